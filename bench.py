@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the detect-to-track custom-op hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: PointwiseCorrelation
+forward + backward at BASELINE.json's metric shape (B=8, C=256, 38x63, d_max=8, stride 1, f32),
+called through the C ABI of libd2t_ops.so exactly as the autograd Function calls it (same entry
+points, caller-allocated outputs, torch's current stream).  Inputs are resident in HBM before the
+timed region.  `--sets` independent buffer sets are rotated (default: > 512 MiB footprint) so the
+256 MiB Infinity Cache does not stand in for HBM.
+
+Multi-GPU: the path shards by frame-pair with no exchange step, so every rank runs the same
+per-GPU workload on its own shard (weak scaling) with NO data-path collective; ranks only meet at
+the timing barriers and the MAX-over-ranks reduction of the elapsed time.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* dense f32 = f32 vector peak
+
+WORKLOADS = {
+    # BASELINE.json metric shape ("north star")
+    "corr_B8_C256_38x63_d8": dict(B=8, C=256, H=38, W=63, d=8, s=1),
+    # BASELINE.json configs[1]
+    "corr_B1_C256_38x63_d8": dict(B=1, C=256, H=38, W=63, d=8, s=1),
+    # shapes the reference model really produces (correlation_tracker.py:57-70)
+    "corr_B1_C512_38x75_d8": dict(B=1, C=512, H=38, W=75, d=8, s=1),
+    "corr_B1_C1024_38x75_d8": dict(B=1, C=1024, H=38, W=75, d=8, s=1),
+    "corr_B1_C2048_38x75_d8": dict(B=1, C=2048, H=38, W=75, d=8, s=1),
+}
+
+
+def corr_counts(B, C, H, W, d, s):
+    """Algorithmic bytes / flops per launch (DESIGN.md "Measurement")."""
+    cw = 2 * d + 1
+    vox = B * H * W * cw * cw
+    cells = 0                                     # window cells the reference actually computes
+    for i in range(H):
+        ni = len(range(max(0, i - d), min(i + d, H), s))
+        for j in range(W):
+            cells += ni * len(range(max(0, j - d), min(j + d, W), s))
+    in_b = B * C * H * W * 4
+    out_b = vox * 4
+    return dict(vox=vox, fwd_bytes=2 * in_b + out_b, bwd_bytes=out_b + 2 * in_b + 2 * in_b,
+                fwd_flops=2 * B * cells * C, bwd_flops=4 * B * cells * C)
+
+
+def host_threads():
+    n = len(os.sched_getaffinity(0))
+    try:                                          # cgroup v2 CPU quota, if any
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cfg, counts, budget_s=12.0):
+    """Time the CPU oracle (a port: the reference has no CPU path, common/cpp_common.hpp:1) on
+    the same workload with all host threads.  Checker code, used here ONLY as a baseline."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import numpy as np
+    threads = host_threads()
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    import oracle as O
+    rng = np.random.default_rng(0)
+    shp = (cfg["B"], cfg["C"], cfg["H"], cfg["W"])
+    cw = 2 * cfg["d"] + 1
+    fm0, fm1 = rng.random(shp, dtype=np.float32), rng.random(shp, dtype=np.float32)
+    g = rng.random((cfg["B"], cfg["H"], cfg["W"], cw, cw), dtype=np.float32)
+    O.corr_fwd(fm0[:1], fm1[:1], cfg["d"], cfg["s"])                    # load + warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        O.corr_fwd(fm0, fm1, cfg["d"], cfg["s"])
+        O.corr_bwd(g, fm0, fm1, cfg["d"], cfg["s"])
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 50:
+            break
+    return dict(value=counts["vox"] * reps / el / 1e9, unit="Gvox/s", cores=threads, kind="port",
+                sample=f"{reps} full steps (fwd+bwd, B={cfg['B']}) of the same workload in {el:.1f} s, "
+                       f"oracle/libd2t_oracle.so with OpenMP over {threads} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="corr_B8_C256_38x63_d8", choices=sorted(WORKLOADS))
+    ap.add_argument("--sets", type=int, default=0, help="rotated buffer sets (0 = enough for > 512 MiB)")
+    ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 tuned only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from detect_to_track.models import _native           # raises ImportError if the HIP library is missing
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    cfg = WORKLOADS[args.workload]
+    B, C, H, W, d, s = (cfg[k] for k in "BCHWds")
+    cw = 2 * d + 1
+    cnt = corr_counts(**cfg)
+    set_bytes = 4 * (B * C * H * W * 4) + 2 * (cnt["vox"] * 4)            # fm0, fm1, g0, g1 + out, gout
+    n_sets = args.sets or max(2, -(-(512 << 20) // set_bytes) + 1)
+
+    torch.manual_seed(rank)                                # per-rank shard of synthetic frame pairs
+    sets = []
+    for _ in range(n_sets):
+        sets.append(dict(
+            fm0=torch.rand(B, C, H, W, device=dev), fm1=torch.rand(B, C, H, W, device=dev),
+            gout=torch.rand(B, H, W, cw, cw, device=dev),
+            out=torch.empty(B, H, W, cw, cw, device=dev),
+            g0=torch.empty(B, C, H, W, device=dev), g1=torch.empty(B, C, H, W, device=dev)))
+    lib = _native.lib
+    wsf_n = lib.d2t_corr_fwd_workspace_bytes(B, C, H, W, d, s, 4)
+    wsb_n = lib.d2t_corr_bwd_workspace_bytes(B, C, H, W, d, s, 4)
+    wsf = torch.empty(max(wsf_n, 1), dtype=torch.uint8, device=dev)
+    wsb = torch.empty(max(wsb_n, 1), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sh = stream.cuda_stream
+
+    def fwd(z):
+        rc = lib.d2t_corr_fwd_f32(z["fm0"].data_ptr(), z["fm1"].data_ptr(), z["out"].data_ptr(),
+                                  B, C, H, W, d, s, wsf.data_ptr(), wsf_n, args.impl, sh)
+        if rc:
+            raise RuntimeError(_native.error_string(rc).decode())
+
+    def bwd(z):
+        rc = lib.d2t_corr_bwd_f32(z["gout"].data_ptr(), z["fm0"].data_ptr(), z["fm1"].data_ptr(),
+                                  z["g0"].data_ptr(), z["g1"].data_ptr(),
+                                  B, C, H, W, d, s, wsb.data_ptr(), wsb_n, args.impl, sh)
+        if rc:
+            raise RuntimeError(_native.error_string(rc).decode())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        z = sets[i % n_sets]
+        fwd(z)
+        bwd(z)
+
+    K = args.steps
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]   # recorded on the launch stream
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        z = sets[(args.warmup + i) % n_sets]
+        ev[3 * i].record(stream)
+        fwd(z)
+        ev[3 * i + 1].record(stream)
+        bwd(z)
+        ev[3 * i + 2].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t_fwd = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K)) / K * 1e-3      # s per launch
+    t_bwd = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)) / K * 1e-3
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms = elapsed / K * 1e3
+        value = world * cnt["vox"] * K / elapsed / 1e9
+
+        def roof(name, t, nbytes, flops):
+            return dict(kernel=name, us=t * 1e6,
+                        hbm=dict(achieved=nbytes / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=nbytes / t / 1e9 / HBM_PEAK_GBS),
+                        mfma=dict(achieved=flops / t / 1e12, peak=FP32_MATRIX_PEAK_TF, unit="TFLOP/s",
+                                  frac=flops / t / 1e12 / FP32_MATRIX_PEAK_TF))
+        kernels = [roof("corr_fwd", t_fwd, cnt["fwd_bytes"], cnt["fwd_flops"]),
+                   roof("corr_bwd", t_bwd, cnt["bwd_bytes"], cnt["bwd_flops"])]
+        dom = max(kernels, key=lambda r: r["us"])
+        # The correlation is f32-FMA-bound at this shape (AI 34-42 F/B vs a 19.7 F/B ridge,
+        # SURVEY.md F10), so the binding roof of the dominant kernel is the f32 matrix/vector peak;
+        # the HBM view BASELINE.json's metric asks for is reported beside it for every kernel.
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(args.workload, {}).get(dom["kernel"])
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "PointwiseCorrelation fwd+bwd Gvox/s (and % HBM roofline) at B=8 C=256 38×63 d=8",
+            "value": value, "unit": "Gvox/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, **cfg, "per_gpu_batch": B, "global_batch": B * world,
+                       "buffer_sets": n_sets, "impl": args.impl, "parallelism": f"shard{world}"},
+            "roofline": {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["mfma"]["achieved"],
+                         "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": dom["mfma"]["frac"],
+                         "traffic": traffic, "launch_us": dom["us"]},
+            "kernels": kernels,
+            "fwd_gvox_per_s": cnt["vox"] / t_fwd / 1e9, "bwd_gvox_per_s": cnt["vox"] / t_bwd / 1e9,
+            "pct_hbm_roofline_fwd": 100 * kernels[0]["hbm"]["frac"],
+            "pct_hbm_roofline_bwd": 100 * kernels[1]["hbm"]["frac"],
+            "host_ms_per_step_minus_device": ms - (t_fwd + t_bwd) * 1e3,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, cnt)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,260 @@
+// d2t_capi.hip -- the extern "C" surface declared in include/d2t_ops.h.
+//
+// Argument validation, int32 range guards, workspace accounting and dispatch between the
+// tuned gfx950 kernels and the type-generic ones.  No allocation, no synchronisation, no
+// mutable global state.
+#include "d2t_kernels.hpp"
+#include "d2t_tuned.hpp"
+
+using namespace d2t;
+
+namespace {
+
+inline hipStream_t as_stream(d2t_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// common checks for the correlation entry points
+int check_corr(const void* a, const void* b, const void* c, int B, int C, int H, int W, int d, int s)
+{
+    if (B < 0 || C < 0 || H < 0 || W < 0 || d < 0 || s < 1) return D2T_EINVAL;
+    const long long cw = 2LL * d + 1;
+    const long long out_n = 1LL * B * H * W * cw * cw;
+    const long long in_n = 1LL * B * C * H * W;
+    if (!fits_i32(cw * cw) || !fits_i32(1LL * B * H * W) || !fits_i32(out_n) || !fits_i32(in_n)) return D2T_ETOOBIG;
+    if (in_n > 0 && (!a || !b)) return D2T_EINVAL;
+    if (out_n > 0 && !c) return D2T_EINVAL;
+    return D2T_OK;
+}
+
+int check_pool(const void* fm, const void* rois, const void* out, int R, int C, int H, int W, int k)
+{
+    if (R < 0 || C < 0 || H < 0 || W < 0 || k < 1) return D2T_EINVAL;
+    const long long out_n = 1LL * R * C * k * k;
+    const long long in_n = 1LL * C * H * W;
+    if (!fits_i32(out_n) || !fits_i32(in_n) || !fits_i32(4LL * R * k * k)) return D2T_ETOOBIG;
+    if (in_n > 0 && !fm) return D2T_EINVAL;
+    if (R > 0 && !rois) return D2T_EINVAL;
+    if (out_n > 0 && !out) return D2T_EINVAL;
+    return D2T_OK;
+}
+
+inline size_t bins_bytes(int R, int k) { return align_up((size_t)R * k * k * 4 * sizeof(int32_t), 256); }
+
+}  // namespace
+
+extern "C" {
+
+int d2t_version(void) { return 100; }
+
+const char* d2t_error_string(int code)
+{
+    switch (code) {
+        case D2T_OK: return "ok";
+        case D2T_EINVAL: return "invalid argument (null pointer, negative extent, stride < 1 or k < 1)";
+        case D2T_ETOOBIG: return "an element count does not fit int32";
+        case D2T_EWS: return "workspace missing or too small";
+        default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown d2t error";
+    }
+}
+
+// ------------------------------------------------------------------ correlation
+size_t d2t_corr_fwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size)
+{
+    return elem_size == 4 ? tuned::corr_fwd_ws_bytes(B, C, H, W, d, stride) : 0;
+}
+size_t d2t_corr_bwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size)
+{
+    return elem_size == 4 ? tuned::corr_bwd_ws_bytes(B, C, H, W, d, stride) : 0;
+}
+
+int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int stride,
+                     void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
+{
+    int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
+    if (rc != D2T_OK) return rc;
+    if (impl != D2T_IMPL_GENERIC && tuned::corr_fwd_supported(B, C, H, W, d, stride)) {
+        if (ws_bytes < tuned::corr_fwd_ws_bytes(B, C, H, W, d, stride)) return D2T_EWS;
+        return tuned::corr_fwd_f32(fm0, fm1, out, B, C, H, W, d, stride, ws, as_stream(stream));
+    }
+    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;     // tuned path demanded but not applicable
+    return corr_fwd_generic<float>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
+}
+
+int d2t_corr_fwd_f64(const double* fm0, const double* fm1, double* out, int B, int C, int H, int W, int d, int stride,
+                     void*, size_t, int impl, d2t_stream_t stream)
+{
+    int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
+    if (rc != D2T_OK) return rc;
+    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    return corr_fwd_generic<double>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
+}
+
+int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* gfm0, float* gfm1,
+                     int B, int C, int H, int W, int d, int stride,
+                     void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
+{
+    int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
+    if (rc != D2T_OK) return rc;
+    if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
+    if (impl != D2T_IMPL_GENERIC && tuned::corr_bwd_supported(B, C, H, W, d, stride)) {
+        if (ws_bytes < tuned::corr_bwd_ws_bytes(B, C, H, W, d, stride)) return D2T_EWS;
+        return tuned::corr_bwd_f32(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, ws, as_stream(stream));
+    }
+    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    return corr_bwd_generic<float>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
+}
+
+int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1, double* gfm0, double* gfm1,
+                     int B, int C, int H, int W, int d, int stride,
+                     void*, size_t, int impl, d2t_stream_t stream)
+{
+    int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
+    if (rc != D2T_OK) return rc;
+    if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
+    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    return corr_bwd_generic<double>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
+}
+
+// ------------------------------------------------------------------ roipool
+size_t d2t_roipool_fwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size)
+{
+    return elem_size == 4 ? tuned::roipool_fwd_ws_bytes(R, C, H, W, k) : 0;
+}
+size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size)
+{
+    const size_t generic = bins_bytes(R, k);
+    const size_t t = elem_size == 4 ? tuned::roipool_bwd_ws_bytes(R, C, H, W, k) : 0;
+    return generic > t ? generic : t;
+}
+
+int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int k,
+                        void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
+{
+    int rc = check_pool(fm, rois, out, R, C, H, W, k);
+    if (rc != D2T_OK) return rc;
+    if (impl != D2T_IMPL_GENERIC && tuned::roipool_fwd_supported(R, C, H, W, k)) {
+        if (ws_bytes < tuned::roipool_fwd_ws_bytes(R, C, H, W, k) || (!ws && ws_bytes)) return D2T_EWS;
+        return tuned::roipool_fwd_f32(fm, rois, out, R, C, H, W, k, ws, as_stream(stream));
+    }
+    return roipool_fwd_generic<float>(fm, rois, out, R, C, H, W, k, as_stream(stream));
+}
+
+int d2t_roipool_fwd_f64(const double* fm, const double* rois, double* out, int R, int C, int H, int W, int k,
+                        void*, size_t, int, d2t_stream_t stream)
+{
+    int rc = check_pool(fm, rois, out, R, C, H, W, k);
+    if (rc != D2T_OK) return rc;
+    return roipool_fwd_generic<double>(fm, rois, out, R, C, H, W, k, as_stream(stream));
+}
+
+int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int k,
+                        void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
+{
+    int rc = check_pool(gin, rois, gout, R, C, H, W, k);
+    if (rc != D2T_OK) return rc;
+    if (impl != D2T_IMPL_GENERIC && tuned::roipool_bwd_supported(R, C, H, W, k)) {
+        if (!ws || ws_bytes < tuned::roipool_bwd_ws_bytes(R, C, H, W, k)) return D2T_EWS;
+        return tuned::roipool_bwd_f32(gout, rois, gin, R, C, H, W, k, ws, as_stream(stream));
+    }
+    if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
+    return roipool_bwd_generic<float>(gout, rois, gin, static_cast<int32_t*>(ws), R, C, H, W, k, as_stream(stream));
+}
+
+int d2t_roipool_bwd_f64(const double* gout, const double* rois, double* gin, int R, int C, int H, int W, int k,
+                        void* ws, size_t ws_bytes, int, d2t_stream_t stream)
+{
+    int rc = check_pool(gin, rois, gout, R, C, H, W, k);
+    if (rc != D2T_OK) return rc;
+    if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
+    return roipool_bwd_generic<double>(gout, rois, gin, static_cast<int32_t*>(ws), R, C, H, W, k, as_stream(stream));
+}
+
+// ------------------------------------------------------------------ psroipool
+size_t d2t_psroipool_fwd_workspace_bytes(int, int, int, int, int, int) { return 0; }
+size_t d2t_psroipool_bwd_workspace_bytes(int R, int nT, int H, int W, int k, int elem_size)
+{
+    const size_t generic = bins_bytes(R, k);
+    const size_t t = elem_size == 4 ? tuned::psroipool_bwd_ws_bytes(R, nT, H, W, k) : 0;
+    return generic > t ? generic : t;
+}
+
+static int check_ps(const void* fm, const void* rois, const void* out, int R, int nT, int H, int W, int k)
+{
+    if (nT < 0 || k < 1) return D2T_EINVAL;
+    if (!fits_i32(1LL * nT * k * k)) return D2T_ETOOBIG;
+    int rc = check_pool(fm, rois, out, R, nT * k * k, H, W, 1);    // input side: nT*k*k channels
+    if (rc != D2T_OK) return rc;
+    if (!fits_i32(1LL * R * nT * k * k) || !fits_i32(4LL * R * k * k)) return D2T_ETOOBIG;
+    return D2T_OK;
+}
+
+int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int k,
+                          void*, size_t, int, d2t_stream_t stream)
+{
+    int rc = check_ps(fm, rois, out, R, nT, H, W, k);
+    if (rc != D2T_OK) return rc;
+    return psroipool_fwd_generic<float>(fm, rois, out, R, nT, H, W, k, as_stream(stream));
+}
+
+int d2t_psroipool_fwd_f64(const double* fm, const double* rois, double* out, int R, int nT, int H, int W, int k,
+                          void*, size_t, int, d2t_stream_t stream)
+{
+    int rc = check_ps(fm, rois, out, R, nT, H, W, k);
+    if (rc != D2T_OK) return rc;
+    return psroipool_fwd_generic<double>(fm, rois, out, R, nT, H, W, k, as_stream(stream));
+}
+
+int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
+                          void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
+{
+    int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
+    if (rc != D2T_OK) return rc;
+    if (impl != D2T_IMPL_GENERIC && tuned::psroipool_bwd_supported(R, nT, H, W, k)) {
+        if (!ws || ws_bytes < tuned::psroipool_bwd_ws_bytes(R, nT, H, W, k)) return D2T_EWS;
+        return tuned::psroipool_bwd_f32(gout, rois, gin, R, nT, H, W, k, ws, as_stream(stream));
+    }
+    if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
+    return psroipool_bwd_generic<float>(gout, rois, gin, static_cast<int32_t*>(ws), R, nT, H, W, k, as_stream(stream));
+}
+
+int d2t_psroipool_bwd_f64(const double* gout, const double* rois, double* gin, int R, int nT, int H, int W, int k,
+                          void* ws, size_t ws_bytes, int, d2t_stream_t stream)
+{
+    int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
+    if (rc != D2T_OK) return rc;
+    if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
+    return psroipool_bwd_generic<double>(gout, rois, gin, static_cast<int32_t*>(ws), R, nT, H, W, k, as_stream(stream));
+}
+
+// ------------------------------------------------------------------ introspection
+#define D2T_BINS(NAME, T, FN)                                                                          \
+    int NAME(const T* rois, int32_t* bounds, int R, int H, int W, int k, d2t_stream_t stream)           \
+    {                                                                                                  \
+        if (R < 0 || H < 0 || W < 0 || k < 1) return D2T_EINVAL;                                        \
+        if (!fits_i32(4LL * R * k * k)) return D2T_ETOOBIG;                                             \
+        if (R > 0 && (!rois || !bounds)) return D2T_EINVAL;                                             \
+        return FN<T>(rois, bounds, R, H, W, k, as_stream(stream));                                      \
+    }
+D2T_BINS(d2t_roipool_bins_f32, float, roipool_bins)
+D2T_BINS(d2t_roipool_bins_f64, double, roipool_bins)
+D2T_BINS(d2t_psroipool_bins_f32, float, psroipool_bins)
+D2T_BINS(d2t_psroipool_bins_f64, double, psroipool_bins)
+
+int d2t_psroipool_channels(int32_t* channels, int nT, int k, d2t_stream_t stream)
+{
+    if (nT < 0 || k < 1) return D2T_EINVAL;
+    if (!fits_i32(1LL * nT * k * k)) return D2T_ETOOBIG;
+    if (nT > 0 && !channels) return D2T_EINVAL;
+    return psroipool_channels(channels, nT, k, as_stream(stream));
+}
+
+int d2t_corr_mask(uint8_t* mask, int H, int W, int d, int stride, d2t_stream_t stream)
+{
+    if (H < 0 || W < 0 || d < 0 || stride < 1) return D2T_EINVAL;
+    if (!fits_i32(1LL * H * W * (2LL * d + 1) * (2LL * d + 1))) return D2T_ETOOBIG;
+    if (1LL * H * W > 0 && !mask) return D2T_EINVAL;
+    return corr_mask(mask, H, W, d, stride, as_stream(stream));
+}
+
+}  // extern "C"

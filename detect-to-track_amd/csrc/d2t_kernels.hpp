@@ -1,0 +1,28 @@
+// d2t_kernels.hpp -- internal launch interface between the C ABI (d2t_capi.hip) and the
+// kernel translation units.  Every launcher is asynchronous on `stream`, allocates
+// nothing, and returns D2T_OK or a hipError_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "d2t_common.hpp"
+
+namespace d2t {
+
+// ---- type-generic, reference-order kernels (d2t_generic.hip); f32 and f64 ----
+template <typename T> int corr_fwd_generic(const T* fm0, const T* fm1, T* out,
+                                           int B, int C, int H, int W, int d, int s, hipStream_t st);
+template <typename T> int corr_bwd_generic(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1,
+                                           int B, int C, int H, int W, int d, int s, hipStream_t st);
+template <typename T> int roipool_fwd_generic(const T* fm, const T* rois, T* out,
+                                              int R, int C, int H, int W, int k, hipStream_t st);
+template <typename T> int roipool_bwd_generic(const T* gout, const T* rois, T* gin, int32_t* bins,
+                                              int R, int C, int H, int W, int k, hipStream_t st);
+template <typename T> int psroipool_fwd_generic(const T* fm, const T* rois, T* out,
+                                                int R, int nT, int H, int W, int k, hipStream_t st);
+template <typename T> int psroipool_bwd_generic(const T* gout, const T* rois, T* gin, int32_t* cells,
+                                                int R, int nT, int H, int W, int k, hipStream_t st);
+template <typename T> int roipool_bins(const T* rois, int32_t* bounds, int R, int H, int W, int k, hipStream_t st);
+template <typename T> int psroipool_bins(const T* rois, int32_t* bounds, int R, int H, int W, int k, hipStream_t st);
+int psroipool_channels(int32_t* ch, int nT, int k, hipStream_t st);
+int corr_mask(uint8_t* mask, int H, int W, int d, int s, hipStream_t st);
+
+}  // namespace d2t

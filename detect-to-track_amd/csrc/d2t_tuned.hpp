@@ -1,0 +1,37 @@
+// d2t_tuned.hpp -- interface of the gfx950-tuned f32 kernels.  Each op exposes
+//   *_supported(...)  host predicate: do the kernel's assumptions hold for this shape?
+//   *_ws_bytes(...)   device scratch it needs (0 = none)
+//   *_f32(...)        async launcher; returns D2T_OK or a hipError_t
+// The C ABI falls back to the type-generic kernels when *_supported is false.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "d2t_common.hpp"
+
+namespace d2t { namespace tuned {
+
+bool   corr_fwd_supported(int B, int C, int H, int W, int d, int s);
+size_t corr_fwd_ws_bytes(int B, int C, int H, int W, int d, int s);
+int    corr_fwd_f32(const float* fm0, const float* fm1, float* out,
+                    int B, int C, int H, int W, int d, int s, void* ws, hipStream_t st);
+
+bool   corr_bwd_supported(int B, int C, int H, int W, int d, int s);
+size_t corr_bwd_ws_bytes(int B, int C, int H, int W, int d, int s);
+int    corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
+                    int B, int C, int H, int W, int d, int s, void* ws, hipStream_t st);
+
+bool   roipool_fwd_supported(int R, int C, int H, int W, int k);
+size_t roipool_fwd_ws_bytes(int R, int C, int H, int W, int k);
+int    roipool_fwd_f32(const float* fm, const float* rois, float* out,
+                       int R, int C, int H, int W, int k, void* ws, hipStream_t st);
+
+bool   roipool_bwd_supported(int R, int C, int H, int W, int k);
+size_t roipool_bwd_ws_bytes(int R, int C, int H, int W, int k);
+int    roipool_bwd_f32(const float* gout, const float* rois, float* gin,
+                       int R, int C, int H, int W, int k, void* ws, hipStream_t st);
+
+bool   psroipool_bwd_supported(int R, int nT, int H, int W, int k);
+size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k);
+int    psroipool_bwd_f32(const float* gout, const float* rois, float* gin,
+                         int R, int nT, int H, int W, int k, void* ws, hipStream_t st);
+
+}}  // namespace d2t::tuned

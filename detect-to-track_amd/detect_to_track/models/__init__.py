@@ -1,0 +1,16 @@
+"""Op layer of detect_to_track, MI355X-native.
+
+Re-exports the three custom ops under the names the reference's model graph imports
+(reference models/__init__.py:3-5; callers correlation_tracker.py:29-30 and rfcn.py:23).
+Importing this package loads libd2t_ops.so and raises ImportError if it has not been built.
+"""
+from . import _native  # noqa: F401  (loads the HIP library; fails loudly when absent)
+from .ps_roipool.ps_roipool import PSROIPool, PSROIPoolFunction
+from .pointwise_correlation.pointwise_correlation import PointwiseCorrelation, PointwiseCorrelationFunction
+from .roipool.roipool import ROIPool, ROIPoolFunction
+
+__all__ = [
+    "PSROIPool", "PSROIPoolFunction",
+    "PointwiseCorrelation", "PointwiseCorrelationFunction",
+    "ROIPool", "ROIPoolFunction",
+]

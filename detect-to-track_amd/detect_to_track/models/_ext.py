@@ -1,0 +1,225 @@
+"""Tensor-level entry points with the names and argument order of the reference's pybind
+module ``_ext`` (pointwise_correlation.cpp:51-62, roipool.cpp:48-59, ps_roipool.cpp:50-61):
+
+    pointwise_correlation_forward(FM0, FM1, d_max, stride) -> out
+    pointwise_correlation_backward(grad_out, FM0, FM1, d_max, stride) -> (grad_FM0, grad_FM1)
+    roipool_forward(FM, rois, r_hw) -> out
+    roipool_backward(grad_out, rois, i_h, i_w) -> grad_FM
+    ps_roipool_forward(FM, rois, n_targets, r_hw) -> out
+    ps_roipool_backward(grad_out, rois, i_h, i_w) -> grad_FM
+
+Each validates its tensors the way the reference's CHECK_INPUT does (common/cpp_common.hpp:1-3:
+device first, then contiguity; both RuntimeError), allocates the outputs with ``torch.empty``
+(the kernels write every element, including the structural zeros the reference gets from
+``at::zeros``), and launches the HIP kernels of libd2t_ops.so on the caller's current stream.
+"""
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from . import _native
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _check_input(x: Tensor, name: str) -> None:
+    if not isinstance(x, Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(x).__name__}")
+    if not x.is_cuda:
+        raise RuntimeError("CPU op not implemented")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _suffix(x: Tensor, name: str) -> str:
+    try:
+        return _SUFFIX[x.dtype]
+    except KeyError:
+        raise RuntimeError(f'"{name}" not implemented for \'{str(x.dtype).replace("torch.", "")}\'') from None
+
+
+def _same(x: Tensor, ref: Tensor, xname: str, refname: str) -> None:
+    if x.dtype != ref.dtype:
+        raise RuntimeError(f"expected scalar type {ref.dtype} for {xname} (dtype of {refname}) but found {x.dtype}")
+    if x.device != ref.device:
+        raise RuntimeError(f"{xname} is on {x.device} but {refname} is on {ref.device}")
+
+
+def _workspace(nbytes: int, like: Tensor):
+    if nbytes == 0:
+        return None, 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+    return ws, nbytes
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream(t: Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# --------------------------------------------------------------------------- correlation
+def pointwise_correlation_forward(FM0: Tensor, FM1: Tensor, d_max: int, stride: int,
+                                  impl: int = _native.IMPL_AUTO) -> Tensor:
+    _check_input(FM0, "FM0")
+    _check_input(FM1, "FM1")
+    sfx = _suffix(FM0, "pointwiseCorrelationsKernelForward")
+    _same(FM1, FM0, "FM1", "FM0")
+    if FM0.dim() != 4 or FM1.shape != FM0.shape:
+        raise RuntimeError(f"FM0 and FM1 must both be (B, C, H, W); got {tuple(FM0.shape)} and {tuple(FM1.shape)}")
+    d_max, stride = int(d_max), int(stride)
+    B, C, H, W = FM0.shape
+    cw = 2 * d_max + 1
+    with torch.cuda.device(FM0.device):
+        out = torch.empty((B, H, W, cw, cw), dtype=FM0.dtype, device=FM0.device)
+        ws, n = _workspace(_native.lib.d2t_corr_fwd_workspace_bytes(B, C, H, W, d_max, stride, FM0.element_size()), FM0)
+        rc = getattr(_native.lib, f"d2t_corr_fwd_{sfx}")(
+            FM0.data_ptr(), FM1.data_ptr(), out.data_ptr(), B, C, H, W, d_max, stride,
+            _ptr(ws), n, impl, _stream(FM0))
+    _native.check(rc, "pointwise_correlation_forward")
+    return out
+
+
+def pointwise_correlation_backward(grad_out: Tensor, FM0: Tensor, FM1: Tensor, d_max: int, stride: int,
+                                   impl: int = _native.IMPL_AUTO) -> Tuple[Tensor, Tensor]:
+    _check_input(grad_out, "gradOut")
+    _check_input(FM0, "FM0")
+    _check_input(FM1, "FM1")
+    sfx = _suffix(FM0, "pointwiseCorrelationsKernelBackward")
+    _same(FM1, FM0, "FM1", "FM0")
+    _same(grad_out, FM0, "gradOut", "FM0")
+    d_max, stride = int(d_max), int(stride)
+    B, C, H, W = FM0.shape
+    cw = 2 * d_max + 1
+    if FM1.shape != FM0.shape or tuple(grad_out.shape) != (B, H, W, cw, cw):
+        raise RuntimeError(
+            f"shape mismatch: FM0 {tuple(FM0.shape)}, FM1 {tuple(FM1.shape)}, gradOut {tuple(grad_out.shape)} "
+            f"(expected gradOut {(B, H, W, cw, cw)})")
+    with torch.cuda.device(FM0.device):
+        g0 = torch.empty_like(FM0)
+        g1 = torch.empty_like(FM1)
+        ws, n = _workspace(_native.lib.d2t_corr_bwd_workspace_bytes(B, C, H, W, d_max, stride, FM0.element_size()), FM0)
+        rc = getattr(_native.lib, f"d2t_corr_bwd_{sfx}")(
+            grad_out.data_ptr(), FM0.data_ptr(), FM1.data_ptr(), g0.data_ptr(), g1.data_ptr(),
+            B, C, H, W, d_max, stride, _ptr(ws), n, impl, _stream(FM0))
+    _native.check(rc, "pointwise_correlation_backward")
+    return g0, g1
+
+
+# --------------------------------------------------------------------------- roipool
+def _check_rois(rois: Tensor, like: Tensor, likename: str) -> int:
+    _check_input(rois, "rois")
+    _same(rois, like, "rois", likename)
+    if rois.dim() != 2 or rois.size(1) != 4:
+        raise RuntimeError(f"rois must be (|R|, 4) ijhw fractional boxes, got {tuple(rois.shape)}")
+    return rois.size(0)
+
+
+def roipool_forward(FM: Tensor, rois: Tensor, r_hw: int, impl: int = _native.IMPL_AUTO) -> Tensor:
+    _check_input(FM, "FM")
+    sfx = _suffix(FM, "ROIPoolKernelForward")
+    R = _check_rois(rois, FM, "FM")
+    if FM.dim() != 3:
+        raise RuntimeError(f"FM must be (C, H, W), got {tuple(FM.shape)}")
+    r_hw = int(r_hw)
+    C, H, W = FM.shape
+    with torch.cuda.device(FM.device):
+        out = torch.empty((R, C, r_hw, r_hw), dtype=FM.dtype, device=FM.device)
+        ws, n = _workspace(_native.lib.d2t_roipool_fwd_workspace_bytes(R, C, H, W, r_hw, FM.element_size()), FM)
+        rc = getattr(_native.lib, f"d2t_roipool_fwd_{sfx}")(
+            FM.data_ptr(), rois.data_ptr(), out.data_ptr(), R, C, H, W, r_hw, _ptr(ws), n, impl, _stream(FM))
+    _native.check(rc, "roipool_forward")
+    return out
+
+
+def roipool_backward(grad_out: Tensor, rois: Tensor, i_h: int, i_w: int, impl: int = _native.IMPL_AUTO) -> Tensor:
+    _check_input(grad_out, "gradOut")
+    sfx = _suffix(grad_out, "ROIPoolKernelBackward")
+    R = _check_rois(rois, grad_out, "gradOut")
+    if grad_out.dim() != 4 or grad_out.size(0) != R or grad_out.size(2) != grad_out.size(3):
+        raise RuntimeError(f"gradOut must be (|R|, C, k, k) with |R| = {R}, got {tuple(grad_out.shape)}")
+    _, C, k, _ = grad_out.shape
+    H, W = int(i_h), int(i_w)
+    with torch.cuda.device(grad_out.device):
+        gin = torch.empty((C, H, W), dtype=grad_out.dtype, device=grad_out.device)
+        ws, n = _workspace(_native.lib.d2t_roipool_bwd_workspace_bytes(R, C, H, W, k, grad_out.element_size()), grad_out)
+        rc = getattr(_native.lib, f"d2t_roipool_bwd_{sfx}")(
+            grad_out.data_ptr(), rois.data_ptr(), gin.data_ptr(), R, C, H, W, k, _ptr(ws), n, impl, _stream(grad_out))
+    _native.check(rc, "roipool_backward")
+    return gin
+
+
+# --------------------------------------------------------------------------- psroipool
+def ps_roipool_forward(FM: Tensor, rois: Tensor, n_targets: int, r_hw: int, impl: int = _native.IMPL_AUTO) -> Tensor:
+    _check_input(FM, "FM")
+    sfx = _suffix(FM, "psROIPoolKernelForward")
+    R = _check_rois(rois, FM, "FM")
+    n_targets, r_hw = int(n_targets), int(r_hw)
+    if FM.dim() != 3 or FM.size(0) != n_targets * r_hw * r_hw:
+        # the reference's launcher never checks this (ps_roipool_cuda.cu:144-174) and would read
+        # out of bounds; the Function raises ValueError before reaching here (ps_roipool.py:44-49)
+        raise RuntimeError(f"FM must be ({n_targets * r_hw * r_hw}, H, W), got {tuple(FM.shape)}")
+    _, H, W = FM.shape
+    with torch.cuda.device(FM.device):
+        out = torch.empty((R, n_targets, r_hw, r_hw), dtype=FM.dtype, device=FM.device)
+        rc = getattr(_native.lib, f"d2t_psroipool_fwd_{sfx}")(
+            FM.data_ptr(), rois.data_ptr(), out.data_ptr(), R, n_targets, H, W, r_hw, 0, 0, impl, _stream(FM))
+    _native.check(rc, "ps_roipool_forward")
+    return out
+
+
+def ps_roipool_backward(grad_out: Tensor, rois: Tensor, i_h: int, i_w: int, impl: int = _native.IMPL_AUTO) -> Tensor:
+    _check_input(grad_out, "gradOut")
+    sfx = _suffix(grad_out, "psROIPoolKernelBackward")
+    R = _check_rois(rois, grad_out, "gradOut")
+    if grad_out.dim() != 4 or grad_out.size(0) != R or grad_out.size(2) != grad_out.size(3):
+        raise RuntimeError(f"gradOut must be (|R|, nT, k, k) with |R| = {R}, got {tuple(grad_out.shape)}")
+    _, nT, k, _ = grad_out.shape
+    H, W = int(i_h), int(i_w)
+    with torch.cuda.device(grad_out.device):
+        gin = torch.empty((nT * k * k, H, W), dtype=grad_out.dtype, device=grad_out.device)
+        ws, n = _workspace(_native.lib.d2t_psroipool_bwd_workspace_bytes(R, nT, H, W, k, grad_out.element_size()), grad_out)
+        rc = getattr(_native.lib, f"d2t_psroipool_bwd_{sfx}")(
+            grad_out.data_ptr(), rois.data_ptr(), gin.data_ptr(), R, nT, H, W, k, _ptr(ws), n, impl, _stream(grad_out))
+    _native.check(rc, "ps_roipool_backward")
+    return gin
+
+
+# --------------------------------------------------------------------------- introspection
+def roipool_bins(rois: Tensor, i_h: int, i_w: int, r_hw: int, position_sensitive: bool = False) -> Tensor:
+    """(|R|, k, k, 4) int32 pixel bounds {i0, i1, j0, j1} computed by the device code the
+    pooling kernels use (bit-exact parity of index arithmetic)."""
+    _check_input(rois, "rois")
+    sfx = _suffix(rois, "bins")
+    R = rois.size(0)
+    op = "psroipool" if position_sensitive else "roipool"
+    with torch.cuda.device(rois.device):
+        out = torch.empty((R, r_hw, r_hw, 4), dtype=torch.int32, device=rois.device)
+        rc = getattr(_native.lib, f"d2t_{op}_bins_{sfx}")(
+            rois.data_ptr(), out.data_ptr(), R, int(i_h), int(i_w), int(r_hw), _stream(rois))
+    _native.check(rc, f"{op}_bins")
+    return out
+
+
+def ps_roipool_channels(n_targets: int, r_hw: int, device) -> Tensor:
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        out = torch.empty((n_targets, r_hw, r_hw), dtype=torch.int32, device=dev)
+        rc = _native.lib.d2t_psroipool_channels(out.data_ptr(), int(n_targets), int(r_hw),
+                                                torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, "psroipool_channels")
+    return out
+
+
+def pointwise_correlation_mask(i_h: int, i_w: int, d_max: int, stride: int, device) -> Tensor:
+    dev = torch.device(device)
+    cw = 2 * int(d_max) + 1
+    with torch.cuda.device(dev):
+        out = torch.empty((i_h, i_w, cw, cw), dtype=torch.uint8, device=dev)
+        rc = _native.lib.d2t_corr_mask(out.data_ptr(), int(i_h), int(i_w), int(d_max), int(stride),
+                                       torch.cuda.current_stream(dev).cuda_stream)
+    _native.check(rc, "corr_mask")
+    return out

@@ -1,0 +1,1 @@
+"""see the module of the same name in this package."""

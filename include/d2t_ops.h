@@ -1,0 +1,142 @@
+/*
+ * d2t_ops.h -- C ABI of libd2t_ops.so: the MI355X (gfx950) implementation of the
+ * detect-to-track custom-op hot path (PointwiseCorrelation, ROIPool, PSROIPool;
+ * forward + backward, f32 and f64).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one function of the
+ * reference's pybind module `_ext` (paths relative to
+ * /root/reference/detect_to_track/models/):
+ *
+ *   d2t_corr_fwd_*       <- pointwise_correlation_forward   pointwise_correlation/pointwise_correlation.cpp:23-33
+ *                           (launcher pointwise_correlation_cuda.cu:178-210)
+ *   d2t_corr_bwd_*       <- pointwise_correlation_backward  pointwise_correlation/pointwise_correlation.cpp:36-48
+ *                           (launcher pointwise_correlation_cuda.cu:214-249)
+ *   d2t_roipool_fwd_*    <- roipool_forward                 roipool/roipool.cpp:22-32   (roipool_cuda.cu:130-157)
+ *   d2t_roipool_bwd_*    <- roipool_backward                roipool/roipool.cpp:35-45   (roipool_cuda.cu:160-190)
+ *   d2t_psroipool_fwd_*  <- ps_roipool_forward              ps_roipool/ps_roipool.cpp:23-34 (ps_roipool_cuda.cu:144-174)
+ *   d2t_psroipool_bwd_*  <- ps_roipool_backward             ps_roipool/ps_roipool.cpp:37-47 (ps_roipool_cuda.cu:177-204)
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no torch / ATen types.  All pointers are DEVICE
+ *     pointers on the current HIP device, contiguous row-major, naturally aligned.
+ *   - The caller allocates every output; the library writes EVERY element of it (the
+ *     reference's launchers pre-zero their outputs with at::zeros; here the structural
+ *     zeros are written by the kernels, so torch.empty is enough).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are
+ *     asynchronous, allocate nothing, synchronise nothing and are graph-capturable.
+ *   - `ws` is caller-provided device scratch of at least the matching
+ *     d2t_*_workspace_bytes(...) bytes (may be NULL when that returns 0).
+ *   - Return value: 0 on success; a negative D2T_E* code for argument errors; a
+ *     positive value is a hipError_t from the launch.  The library keeps no pointers
+ *     after return and has no mutable global state (re-entrant: autograd calls
+ *     backward from another thread).
+ *   - All extents are int32, like the reference's index arithmetic
+ *     (pointwise_correlation_cuda.cu:19-50); shapes whose element count would exceed
+ *     2^31-1 are rejected with D2T_ETOOBIG.
+ *
+ * Layouts
+ *   correlation:  fm0, fm1 (B,C,H,W); out / gout (B,H,W,2d+1,2d+1); gfm0, gfm1 (B,C,H,W)
+ *   roipool:      fm (C,H,W); rois (R,4) = (centre_i, centre_j, height, width) as fractions
+ *                 of the map; out / gout (R,C,k,k); gin (C,H,W)
+ *   psroipool:    fm (nT*k*k,H,W); rois (R,4); out / gout (R,nT,k,k); gin (nT*k*k,H,W)
+ */
+#ifndef D2T_OPS_H
+#define D2T_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* d2t_stream_t; /* hipStream_t */
+
+enum {
+    D2T_OK       = 0,
+    D2T_EINVAL   = -1, /* null pointer, negative extent, stride < 1, k < 1 ... */
+    D2T_ETOOBIG  = -2, /* an element count does not fit int32 */
+    D2T_EWS      = -3  /* workspace missing or too small */
+};
+
+/* library / ABI version (major*100 + minor) and a static message for a return code */
+int         d2t_version(void);
+const char* d2t_error_string(int code);
+
+/* Implementation selector for the f32 correlation kernels (per call, no global state):
+ *   D2T_IMPL_AUTO    the tuned gfx950 path when its preconditions hold, else generic
+ *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)     */
+enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2 };
+
+/* ---------------- PointwiseCorrelation ---------------- */
+size_t d2t_corr_fwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size);
+size_t d2t_corr_bwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size);
+
+int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out,
+                     int B, int C, int H, int W, int d, int stride,
+                     void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_corr_fwd_f64(const double* fm0, const double* fm1, double* out,
+                     int B, int C, int H, int W, int d, int stride,
+                     void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1,
+                     float* gfm0, float* gfm1,
+                     int B, int C, int H, int W, int d, int stride,
+                     void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1,
+                     double* gfm0, double* gfm1,
+                     int B, int C, int H, int W, int d, int stride,
+                     void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+
+/* ---------------- ROIPool (average) ---------------- */
+size_t d2t_roipool_fwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size);
+size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size);
+
+int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out,
+                        int R, int C, int H, int W, int k,
+                        void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_roipool_fwd_f64(const double* fm, const double* rois, double* out,
+                        int R, int C, int H, int W, int k,
+                        void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin,
+                        int R, int C, int H, int W, int k,
+                        void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_roipool_bwd_f64(const double* gout, const double* rois, double* gin,
+                        int R, int C, int H, int W, int k,
+                        void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+
+/* ---------------- PSROIPool (position-sensitive average) ---------------- */
+size_t d2t_psroipool_fwd_workspace_bytes(int R, int nT, int H, int W, int k, int elem_size);
+size_t d2t_psroipool_bwd_workspace_bytes(int R, int nT, int H, int W, int k, int elem_size);
+
+int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out,
+                          int R, int nT, int H, int W, int k,
+                          void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_psroipool_fwd_f64(const double* fm, const double* rois, double* out,
+                          int R, int nT, int H, int W, int k,
+                          void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin,
+                          int R, int nT, int H, int W, int k,
+                          void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_psroipool_bwd_f64(const double* gout, const double* rois, double* gin,
+                          int R, int nT, int H, int W, int k,
+                          void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+
+/* ---------------- integer introspection (parity of index arithmetic) ----------------
+ * These run the SAME device functions the pooling / correlation kernels use and write the
+ * integer quantities the parity contract requires bit-exact:
+ *   bins:     (R,k,k,4) int32 = {i0, i1, j0, j1} pixel bounds of every bin / cell
+ *             (roipool_cuda.cu:47-50, ps_roipool_cuda.cu:51-54)
+ *   channels: (nT,k,k) int32 position-sensitive channel of every output (ps_roipool_cuda.cu:58)
+ *   mask:     (H,W,2d+1,2d+1) uint8, 1 where the correlation loops write
+ *             (pointwise_correlation_cuda.cu:92-93)                                    */
+int d2t_roipool_bins_f32(const float* rois, int32_t* bounds, int R, int H, int W, int k, d2t_stream_t stream);
+int d2t_roipool_bins_f64(const double* rois, int32_t* bounds, int R, int H, int W, int k, d2t_stream_t stream);
+int d2t_psroipool_bins_f32(const float* rois, int32_t* bounds, int R, int H, int W, int k, d2t_stream_t stream);
+int d2t_psroipool_bins_f64(const double* rois, int32_t* bounds, int R, int H, int W, int k, d2t_stream_t stream);
+int d2t_psroipool_channels(int32_t* channels, int nT, int k, d2t_stream_t stream);
+int d2t_corr_mask(uint8_t* mask, int H, int W, int d, int stride, d2t_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2T_OPS_H */

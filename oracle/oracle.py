@@ -1,0 +1,131 @@
+"""numpy front-end of the CPU oracle (oracle/libd2t_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by bench.py's
+cpu_baseline leg -- never by the product package (detect-to-track_amd/), which has no CPU path.
+
+Every function takes / returns C-contiguous numpy arrays of dtype float32 or float64 and
+follows the reference kernel cited in oracle/d2t_oracle_impl.h.
+"""
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "libd2t_oracle.so"
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with gcc (a few seconds)."""
+    src_newer = _LIB_PATH.exists() and any(
+        (_HERE / f).stat().st_mtime > _LIB_PATH.stat().st_mtime for f in ("d2t_oracle.c", "d2t_oracle_impl.h"))
+    if force or src_newer or not _LIB_PATH.exists():
+        subprocess.run(["make", "-C", str(_HERE), "-B", "libd2t_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            build()
+        _lib = ctypes.CDLL(str(_LIB_PATH))
+    return _lib
+
+
+def _sfx(a: np.ndarray) -> str:
+    if a.dtype == np.float32:
+        return "f32"
+    if a.dtype == np.float64:
+        return "f64"
+    raise TypeError(f"oracle supports float32/float64, got {a.dtype}")
+
+
+def _c(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def set_threads(n: int) -> None:
+    os.environ["OMP_NUM_THREADS"] = str(n)
+
+
+def corr_fwd(fm0, fm1, d, s):
+    fm0, fm1 = _c(fm0), _c(fm1)
+    B, C, H, W = fm0.shape
+    cw = 2 * d + 1
+    out = np.empty((B, H, W, cw, cw), dtype=fm0.dtype)
+    getattr(lib(), f"d2t_oracle_corr_fwd_{_sfx(fm0)}")(_p(fm0), _p(fm1), _p(out), B, C, H, W, d, s)
+    return out
+
+
+def corr_bwd(gout, fm0, fm1, d, s):
+    gout, fm0, fm1 = _c(gout), _c(fm0), _c(fm1)
+    B, C, H, W = fm0.shape
+    g0, g1 = np.empty_like(fm0), np.empty_like(fm1)
+    getattr(lib(), f"d2t_oracle_corr_bwd_{_sfx(fm0)}")(_p(gout), _p(fm0), _p(fm1), _p(g0), _p(g1), B, C, H, W, d, s)
+    return g0, g1
+
+
+def corr_mask(H, W, d, s):
+    cw = 2 * d + 1
+    m = np.empty((H, W, cw, cw), dtype=np.uint8)
+    lib().d2t_oracle_corr_mask(_p(m), H, W, d, s)
+    return m
+
+
+def roipool_fwd(fm, rois, k):
+    fm, rois = _c(fm), _c(rois)
+    C, H, W = fm.shape
+    R = rois.shape[0]
+    out = np.empty((R, C, k, k), dtype=fm.dtype)
+    getattr(lib(), f"d2t_oracle_roipool_fwd_{_sfx(fm)}")(_p(fm), _p(rois), _p(out), R, C, H, W, k)
+    return out
+
+
+def roipool_bwd(gout, rois, H, W):
+    gout, rois = _c(gout), _c(rois)
+    R, C, k, _ = gout.shape
+    gin = np.empty((C, H, W), dtype=gout.dtype)
+    getattr(lib(), f"d2t_oracle_roipool_bwd_{_sfx(gout)}")(_p(gout), _p(rois), _p(gin), R, C, H, W, k)
+    return gin
+
+
+def roipool_bins(rois, H, W, k, position_sensitive=False):
+    rois = _c(rois)
+    R = rois.shape[0]
+    out = np.empty((R, k, k, 4), dtype=np.int32)
+    name = "psroipool_bins" if position_sensitive else "roipool_bins"
+    getattr(lib(), f"d2t_oracle_{name}_{_sfx(rois)}")(_p(rois), _p(out), R, H, W, k)
+    return out
+
+
+def psroipool_fwd(fm, rois, nT, k):
+    fm, rois = _c(fm), _c(rois)
+    _, H, W = fm.shape
+    R = rois.shape[0]
+    out = np.empty((R, nT, k, k), dtype=fm.dtype)
+    getattr(lib(), f"d2t_oracle_psroipool_fwd_{_sfx(fm)}")(_p(fm), _p(rois), _p(out), R, nT, H, W, k)
+    return out
+
+
+def psroipool_bwd(gout, rois, H, W):
+    gout, rois = _c(gout), _c(rois)
+    R, nT, k, _ = gout.shape
+    gin = np.empty((nT * k * k, H, W), dtype=gout.dtype)
+    getattr(lib(), f"d2t_oracle_psroipool_bwd_{_sfx(gout)}")(_p(gout), _p(rois), _p(gin), R, nT, H, W, k)
+    return gin
+
+
+def psroipool_channels(nT, k):
+    ch = np.empty((nT, k, k), dtype=np.int32)
+    lib().d2t_oracle_psroipool_channels(_p(ch), nT, k)
+    return ch

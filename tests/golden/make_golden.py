@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from THE REFERENCE'S OWN KERNELS.
+
+Run on an MI355X box (there is no GPU in the build container):
+
+    gpurun -- 'python tests/golden/make_golden.py gpurun_out/golden'
+
+then copy gpurun_out/golden/*.npz into tests/golden/.  The reference modules are the ones
+oracle/ref_build/Makefile compiles, unmodified, from /root/reference (hipcc, gfx950) into
+oracle/_ref/; they travel to the GPU box as built .so files.  Nothing here reads
+/root/reference at run time.
+
+Each fixture holds seeded INPUTS and the reference's OUTPUTS (data only):
+
+  corr_<case>.npz      fm0, fm1, gout, d, s  ->  out, g0, g1, mask
+                       mask = (reference forward of all-ones inputs != 0): the written-cell set
+  roipool_<case>.npz   fm, rois, gout, k     ->  out, gin, bounds
+  psroipool_<case>.npz fm, rois, gout, nT, k ->  out, gin, bounds, channels
+                       bounds (R,k,k,4) int32 {i0,i1,j0,j1}, -1 for bins the reference treats as
+                       empty: recovered from the reference BACKWARD of one-hot gradients (the
+                       non-zero footprint of gradIn is exactly the bin's pixel set)
+                       channels (nT,k,k) int32: recovered from the reference FORWARD of a map whose
+                       channel c is the constant c (needs every cell non-empty: a full-map RoI)
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "oracle" / "_ref"))
+import d2t_ref_corr as ref_corr          # noqa: E402
+import d2t_ref_psroipool as ref_ps       # noqa: E402
+import d2t_ref_roipool as ref_roi        # noqa: E402
+
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ correlation
+def corr_case(name, B, C, H, W, d, s, dtype, seed, out_dir):
+    rng = np.random.default_rng(seed)
+    fm0 = rng.random((B, C, H, W)).astype(dtype)
+    fm1 = rng.random((B, C, H, W)).astype(dtype)
+    cw = 2 * d + 1
+    gout = rng.random((B, H, W, cw, cw)).astype(dtype)
+    out = ref_corr.pointwise_correlation_forward(t(fm0), t(fm1), d, s)
+    g0, g1 = ref_corr.pointwise_correlation_backward(t(gout), t(fm0), t(fm1), d, s)
+    ones = torch.ones((1, 1, H, W), dtype=torch.float32, device=DEV)
+    mask = (ref_corr.pointwise_correlation_forward(ones, ones, d, s)[0] != 0).to(torch.uint8)
+    np.savez_compressed(out_dir / f"corr_{name}.npz", fm0=fm0, fm1=fm1, gout=gout, d=d, s=s,
+                        out=n(out), g0=n(g0), g1=n(g1), mask=n(mask))
+
+
+# ------------------------------------------------------------------ pooling helpers
+def bounds_from_backward(bwd, rois, H, W, k, dtype, channel_of_bin):
+    """Recover integer bin bounds from the reference backward.  gradOut is one-hot per bin,
+    laid out so that bin (i,j) lands in its own input channel."""
+    R = rois.shape[0]
+    bounds = -np.ones((R, k, k, 4), dtype=np.int32)
+    for r in range(R):
+        g = np.zeros((1, k * k, k, k), dtype=dtype) if channel_of_bin is None else np.zeros((1, 1, k, k), dtype=dtype)
+        if channel_of_bin is None:                     # ROIPool: C = k*k channels, channel c lit at bin c
+            for b in range(k * k):
+                g[0, b, b // k, b % k] = 1
+        else:                                          # PSROIPool with nT=1: channel (0+1)*bin = bin
+            g[:] = 1
+        gin = n(bwd(t(g), t(rois[r:r + 1]), H, W))      # (k*k, H, W)
+        for b in range(k * k):
+            nz = np.argwhere(gin[b] != 0)
+            if len(nz):
+                (i0, j0), (i1, j1) = nz.min(0), nz.max(0) + 1
+                assert len(nz) == (i1 - i0) * (j1 - j0), "footprint is not a rectangle"
+                assert np.allclose(gin[b][i0:i1, j0:j1], 1.0 / len(nz), rtol=1e-6), "footprint value is not 1/n"
+                bounds[r, b // k, b % k] = (i0, i1, j0, j1)
+    return bounds
+
+
+ADVERSARIAL_ROIS = [
+    [0.5, 0.5, 0.5, 0.5],        # interior
+    [0.1, 0.1, 0.2, 0.3],        # crosses top/left edge
+    [0.95, 0.9, 0.3, 0.4],       # crosses bottom/right edge
+    [0.5, 0.5, 1.0, 1.0],        # whole map
+    [0.5, 0.5, 2.0, 2.0],        # larger than the map
+    [0.3, 0.7, 0.0, 0.0],        # zero area
+    [1.5, 1.5, 0.2, 0.2],        # fully out of bounds (bottom/right)
+    [-0.5, -0.5, 0.2, 0.2],      # fully out of bounds (top/left)
+    [0.25, 0.75, 0.01, 0.9],     # sliver
+    [0.5, 0.5, 0.123, 0.987],
+    [3.0, 3.0, 0.5, 0.5],        # tests/test_ps_roipool.py:39
+]
+
+
+def roipool_case(name, C, H, W, k, rois, dtype, seed, out_dir):
+    rng = np.random.default_rng(seed)
+    rois = np.asarray(rois, dtype=dtype)
+    R = rois.shape[0]
+    fm = rng.random((C, H, W)).astype(dtype)
+    gout = rng.random((R, C, k, k)).astype(dtype)
+    out = ref_roi.roipool_forward(t(fm), t(rois), k)
+    gin = ref_roi.roipool_backward(t(gout), t(rois), H, W)
+    bounds = bounds_from_backward(ref_roi.roipool_backward, rois, H, W, k, dtype, None)
+    np.savez_compressed(out_dir / f"roipool_{name}.npz", fm=fm, rois=rois, gout=gout, k=k,
+                        out=n(out), gin=n(gin), bounds=bounds)
+
+
+def psroipool_case(name, nT, H, W, k, rois, dtype, seed, out_dir):
+    rng = np.random.default_rng(seed)
+    rois = np.asarray(rois, dtype=dtype)
+    R = rois.shape[0]
+    fm = rng.random((nT * k * k, H, W)).astype(dtype)
+    gout = rng.random((R, nT, k, k)).astype(dtype)
+    out = ref_ps.ps_roipool_forward(t(fm), t(rois), nT, k)
+    gin = ref_ps.ps_roipool_backward(t(gout), t(rois), H, W)
+    bounds = bounds_from_backward(ref_ps.ps_roipool_backward, rois, H, W, k, dtype, "ps")
+    coded = np.broadcast_to(np.arange(nT * k * k, dtype=dtype)[:, None, None], (nT * k * k, H, W)).copy()
+    full = np.asarray([[0.5, 0.5, 1.0, 1.0]], dtype=dtype)
+    channels = np.rint(n(ref_ps.ps_roipool_forward(t(coded), t(full), nT, k))[0]).astype(np.int32)
+    np.savez_compressed(out_dir / f"psroipool_{name}.npz", fm=fm, rois=rois, gout=gout, nT=nT, k=k,
+                        out=n(out), gin=n(gin), bounds=bounds, channels=channels)
+
+
+def random_rois(R, seed, dtype):
+    # centre U(0.15, 0.85)^2, size U(0.05, 0.6)^2
+    rng = np.random.default_rng(seed)
+    return np.concatenate([rng.uniform(0.15, 0.85, (R, 2)), rng.uniform(0.05, 0.6, (R, 2))], 1).astype(dtype)
+
+
+def main():
+    out_dir = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/golden")
+    out_dir.mkdir(parents=True, exist_ok=True)
+    assert torch.cuda.is_available(), "needs the MI355X box"
+    print("device:", torch.cuda.get_device_name(0))
+    seed = 1000
+
+    # reference tests/test_pointwise_correlation.py:8-12 parametrisation (f64), plus f32 twins
+    for s in (1, 2):
+        for B in (1, 2):
+            for hw in (10, 11):
+                for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+                    seed += 1
+                    corr_case(f"t_d3_s{s}_b{B}_c2_hw{hw}_{tag}", B, 2, hw, hw, 3, s, dt, seed, out_dir)
+    # wider / adversarial shapes
+    for name, (B, C, H, W, d, s) in {
+        "d8_c16_12x20": (1, 16, 12, 20, 8, 1), "d8_c16_12x20_s3": (1, 16, 12, 20, 8, 3),
+        "d1_c5_7x9": (2, 5, 7, 9, 1, 1), "d0_c3_4x5": (1, 3, 4, 5, 0, 1),
+        "d8_c64_19x23": (2, 64, 19, 23, 8, 1), "d4_c8_5x3": (1, 8, 5, 3, 4, 1),
+        "d2_c7_9x9_s5": (1, 7, 9, 9, 2, 5),
+    }.items():
+        for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+            seed += 1
+            corr_case(f"{name}_{tag}", B, C, H, W, d, s, dt, seed, out_dir)
+
+    # reference tests/test_roipool.py:10-23
+    test_rois = [[0.5, 0.5, 0.5, 0.5], [0.1, 0.1, 0.2, 0.3]]
+    for k in (5, 6):
+        for H in (10, 11):
+            for W in (10, 11):
+                for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+                    seed += 1
+                    roipool_case(f"t_k{k}_c2_{H}x{W}_{tag}", 2, H, W, k, test_rois, dt, seed, out_dir)
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        seed += 1
+        roipool_case(f"adv_k7_c3_38x63_{tag}", 3, 38, 63, 7, ADVERSARIAL_ROIS, dt, seed, out_dir)
+        seed += 1
+        roipool_case(f"adv_k3_c2_9x14_{tag}", 2, 9, 14, 3, ADVERSARIAL_ROIS, dt, seed, out_dir)
+        seed += 1
+        roipool_case(f"rand_k7_c8_38x63_{tag}", 8, 38, 63, 7, random_rois(24, seed, dt), dt, seed, out_dir)
+
+    # reference tests/test_ps_roipool.py:8-26 and :33-40
+    ps_rois = [[0.5, 0.5, 0.1, 0.1], [0.1, 0.1, 0.2, 0.3], [1.5, 1.5, 0.2, 0.2]]
+    for nT in (1, 2):
+        for k in (6, 7):
+            for H in (10, 11):
+                for W in (10, 11):
+                    for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+                        seed += 1
+                        psroipool_case(f"t_n{nT}_k{k}_{H}x{W}_{tag}", nT, H, W, k, ps_rois, dt, seed, out_dir)
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        seed += 1
+        psroipool_case(f"adv_n3_k7_38x63_{tag}", 3, 38, 63, 7, ADVERSARIAL_ROIS, dt, seed, out_dir)
+        seed += 1
+        psroipool_case(f"adv_n5_k3_9x14_{tag}", 5, 9, 14, 3, ADVERSARIAL_ROIS, dt, seed, out_dir)
+        seed += 1
+        psroipool_case(f"rand_n4_k7_38x75_{tag}", 4, 38, 75, 7, random_rois(24, seed, dt), dt, seed, out_dir)
+    # the known-answer case: constant 10 map, RoI (3,3,.5,.5) -> zeros
+    fm = np.full((2 * 49, 10, 11), 10.0, dtype=np.float32)
+    koa = n(ref_ps.ps_roipool_forward(t(fm), t(np.asarray([[3.0, 3.0, 0.5, 0.5]], np.float32)), 2, 7))
+    np.savez_compressed(out_dir / "psroipool_known_answer_oob.npz", out=koa)
+
+    files = sorted(out_dir.glob("*.npz"))
+    print(f"wrote {len(files)} fixtures, {sum(f.stat().st_size for f in files) / 1e6:.2f} MB -> {out_dir}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+"""GPU parity tests of PointwiseCorrelation (HIP kernels through the C ABI).
+
+Mirrors reference tests/test_pointwise_correlation.py:8-22 (gradcheck, f64) and adds absolute
+parity: against the CPU oracle, against the golden fixtures produced by the reference's own
+kernels, and against those kernels live (oracle/_ref) on larger seeded inputs.
+
+Tolerances: forward values -- the HIP kernels evaluate the same ascending-c FMA chain as the
+reference, so f32/f64 forward outputs are compared BIT-EXACT with the oracle and with the
+reference kernels; gradFM0 likewise (thread-owned order in the reference).  gradFM1 is summed
+with atomics in the reference (order undefined): |delta| <= 1e-5 on the test-file inputs
+(BASELINE.json), rtol 1e-5 elsewhere.  The written-cell mask is compared bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+from torch.autograd import gradcheck
+
+from conftest import golden_files, golden_ids, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _n(x):
+    return x.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("d_max", [3])
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("input_b", [1, 2])
+@pytest.mark.parametrize("input_c", [2])
+@pytest.mark.parametrize("input_hw", [10, 11])
+def test_pointwise_correlation_gradients(d_max, stride, input_b, input_c, input_hw):
+    from detect_to_track.models import PointwiseCorrelation
+    pc = PointwiseCorrelation(d_max, stride).cuda()
+    shape = (input_b, input_c, input_hw, input_hw)
+    fm0 = torch.rand(*shape).double().cuda().requires_grad_(True)
+    fm1 = torch.rand(*shape).double().cuda().requires_grad_(True)
+    assert gradcheck(pc, (fm0, fm1))
+
+
+@pytest.mark.parametrize("path", golden_files("corr"), ids=golden_ids("corr"))
+def test_matches_reference_fixture(path):
+    from detect_to_track.models import _ext
+    g = load_golden(path)
+    d, s = int(g["d"]), int(g["s"])
+    out = _n(_ext.pointwise_correlation_forward(_t(g["fm0"]), _t(g["fm1"]), d, s))
+    np.testing.assert_array_equal(out, g["out"])                      # bit-exact forward
+    g0, g1 = _ext.pointwise_correlation_backward(_t(g["gout"]), _t(g["fm0"]), _t(g["fm1"]), d, s)
+    np.testing.assert_array_equal(_n(g0), g["g0"])                    # thread-owned order: bit-exact
+    np.testing.assert_allclose(_n(g1), g["g1"], rtol=1e-5, atol=1e-5)  # atomics in the reference
+    H, W = g["fm0"].shape[2:]
+    mask = _n(_ext.pointwise_correlation_mask(H, W, d, s, DEV))
+    np.testing.assert_array_equal(mask, g["mask"])
+    assert ((out[0] != 0) <= mask.astype(bool)).all()
+
+
+CASES = [  # (B, C, H, W, d, s)
+    (1, 2, 10, 10, 3, 1), (2, 2, 11, 11, 3, 2), (1, 16, 12, 20, 8, 1), (1, 16, 12, 20, 8, 3),
+    (2, 5, 7, 9, 1, 1), (1, 3, 4, 5, 0, 1), (1, 8, 5, 3, 4, 1), (1, 7, 9, 9, 2, 5),
+    (2, 64, 19, 23, 8, 1), (1, 256, 38, 63, 8, 1), (1, 96, 38, 75, 8, 1), (3, 33, 17, 31, 8, 1),
+    (1, 4, 40, 70, 8, 1), (2, 128, 8, 8, 8, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_matches_oracle(case, dtype, oracle):
+    from detect_to_track.models import _ext
+    B, C, H, W, d, s = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    fm0, fm1 = rng.random((B, C, H, W)).astype(dtype), rng.random((B, C, H, W)).astype(dtype)
+    gout = rng.random((B, H, W, 2 * d + 1, 2 * d + 1)).astype(dtype)
+    out = _n(_ext.pointwise_correlation_forward(_t(fm0), _t(fm1), d, s))
+    np.testing.assert_array_equal(out, oracle.corr_fwd(fm0, fm1, d, s))
+    g0, g1 = _ext.pointwise_correlation_backward(_t(gout), _t(fm0), _t(fm1), d, s)
+    o0, o1 = oracle.corr_bwd(gout, fm0, fm1, d, s)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == np.float32 else dict(rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(_n(g0), o0, **tol)
+    np.testing.assert_allclose(_n(g1), o1, **tol)
+    np.testing.assert_array_equal(_n(_ext.pointwise_correlation_mask(H, W, d, s, DEV)), oracle.corr_mask(H, W, d, s))
+
+
+@pytest.mark.parametrize("impl", [0, 1], ids=["auto", "generic"])
+@pytest.mark.parametrize("case", [(1, 256, 38, 63, 8, 1), (2, 512, 38, 75, 8, 1), (1, 40, 13, 29, 8, 1),
+                                  (2, 2, 10, 10, 3, 1), (1, 260, 21, 18, 8, 1)], ids=str)
+def test_matches_live_reference(case, impl, ref_modules):
+    """HIP kernels vs the reference's own kernels on the same GPU, same inputs."""
+    from detect_to_track.models import _ext
+    ref_corr = ref_modules[0]
+    B, C, H, W, d, s = case
+    torch.manual_seed(1234)
+    fm0 = torch.rand(B, C, H, W, device=DEV)
+    fm1 = torch.rand(B, C, H, W, device=DEV)
+    gout = torch.rand(B, H, W, 2 * d + 1, 2 * d + 1, device=DEV)
+    out = _ext.pointwise_correlation_forward(fm0, fm1, d, s, impl)
+    ref = ref_corr.pointwise_correlation_forward(fm0, fm1, d, s)
+    assert torch.equal(out, ref), f"max |delta| {(out - ref).abs().max().item()}"
+    g0, g1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, d, s, impl)
+    r0, r1 = ref_corr.pointwise_correlation_backward(gout, fm0, fm1, d, s)
+    torch.testing.assert_close(g0, r0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, r1, rtol=1e-5, atol=1e-5)
+
+
+def test_north_star_shape_properties():
+    """B=8 C=256 38x63 d=8 (BASELINE.json metric shape): size-independent properties."""
+    from detect_to_track.models import _ext
+    torch.manual_seed(0)
+    B, C, H, W, d = 8, 256, 38, 63, 8
+    fm0 = torch.rand(B, C, H, W, device=DEV)
+    fm1 = torch.rand(B, C, H, W, device=DEV)
+    out = _ext.pointwise_correlation_forward(fm0, fm1, d, 1)
+    # (1) structural zeros exactly where the mask says, and only there (inputs are > 0)
+    mask = _ext.pointwise_correlation_mask(H, W, d, 1, DEV).bool()
+    assert torch.equal(out != 0, mask.expand(B, -1, -1, -1, -1))
+    assert int(mask.sum()) == 513536
+    # (2) batch independence: item b alone gives the same bits
+    one = _ext.pointwise_correlation_forward(fm0[3:4].contiguous(), fm1[3:4].contiguous(), d, 1)
+    assert torch.equal(one[0], out[3])
+    # (3) the centre cell is the plain channel dot product, bit-exact vs an fp64-free fma chain is
+    #     covered elsewhere; here: against fp64 within fp32 rounding of a 256-term sum
+    ref_c = (fm0.double() * fm1.double()).sum(1)
+    assert torch.allclose(out[..., d, d].double(), ref_c, rtol=1e-5)
+    # (4) linearity in FM0 (exact for power-of-two scaling)
+    out2 = _ext.pointwise_correlation_forward(fm0 * 2, fm1, d, 1)
+    assert torch.equal(out2, out * 2)
+    # (5) adjointness: <out, G> == <FM0, gFM0> == <FM1, gFM1>
+    G = torch.rand_like(out)
+    g0, g1 = _ext.pointwise_correlation_backward(G, fm0, fm1, d, 1)
+    lhs = (out.double() * G.double()).sum()
+    assert torch.allclose(lhs, (fm0.double() * g0.double()).sum(), rtol=1e-5)
+    assert torch.allclose(lhs, (fm1.double() * g1.double()).sum(), rtol=1e-5)
+    # (6) determinism: backward is atomic-free, two runs give identical bits
+    h0, h1 = _ext.pointwise_correlation_backward(G, fm0, fm1, d, 1)
+    assert torch.equal(g0, h0) and torch.equal(g1, h1)
+
+
+def test_empty_and_errors():
+    from detect_to_track.models import PointwiseCorrelation, _ext
+    pc = PointwiseCorrelation(2, 1)
+    out = pc(torch.empty(0, 3, 5, 5, device=DEV), torch.empty(0, 3, 5, 5, device=DEV))
+    assert out.shape == (0, 5, 5, 5, 5)
+    out = pc(torch.rand(1, 0, 5, 5, device=DEV), torch.rand(1, 0, 5, 5, device=DEV))     # C = 0: all zeros
+    assert out.shape == (1, 5, 5, 5, 5) and not out.any()
+    with pytest.raises(RuntimeError, match="CPU op not implemented"):
+        pc(torch.rand(1, 2, 5, 5), torch.rand(1, 2, 5, 5))
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        pc(torch.rand(1, 2, 5, 6, device=DEV).transpose(2, 3), torch.rand(1, 2, 6, 5, device=DEV))
+    with pytest.raises(RuntimeError):
+        pc(torch.rand(1, 2, 5, 5, device=DEV), torch.rand(1, 2, 5, 5, device=DEV).double())
+    with pytest.raises(RuntimeError):
+        _ext.pointwise_correlation_forward(torch.rand(1, 2, 5, 5, device=DEV).half(),
+                                           torch.rand(1, 2, 5, 5, device=DEV).half(), 2, 1)
+
+
+def test_runs_on_current_stream():
+    from detect_to_track.models import _ext
+    s = torch.cuda.Stream()
+    fm0 = torch.rand(1, 8, 9, 9, device=DEV)
+    fm1 = torch.rand(1, 8, 9, 9, device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        a = _ext.pointwise_correlation_forward(fm0, fm1, 2, 1)
+    s.synchronize()
+    b = _ext.pointwise_correlation_forward(fm0, fm1, 2, 1)
+    assert torch.equal(a, b)

@@ -1,0 +1,157 @@
+"""GPU parity tests of PSROIPool (position-sensitive average pooling) through the C ABI.
+
+Mirrors reference tests/test_ps_roipool.py:8-44 (gradcheck f64 incl. an out-of-bounds RoI, and
+the known-answer out-of-bounds -> zeros test) and adds absolute parity against the CPU oracle,
+the reference-generated fixtures and the reference's kernels live.
+
+Bit-exact: cell bounds, the (t+1)*(i*k+j) channel map, forward values (same running-sum order
+as the reference).  Backward: |delta| <= 1e-5 (atomics in the reference, order undefined).
+"""
+import numpy as np
+import pytest
+import torch
+from torch.autograd import gradcheck
+
+from conftest import ADVERSARIAL_ROIS, golden_files, golden_ids, load_golden, random_rois
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL32 = dict(rtol=1e-5, atol=1e-5)
+TOL64 = dict(rtol=1e-12, atol=1e-12)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _n(x):
+    return x.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("n_targets", [1, 2])
+@pytest.mark.parametrize("r_hw", [6, 7])
+@pytest.mark.parametrize("fm_h", [10, 11])
+@pytest.mark.parametrize("fm_w", [10, 11])
+def test_ps_roipool_gradients(n_targets, r_hw, fm_h, fm_w):
+    from detect_to_track.models import PSROIPool
+    pr = PSROIPool(n_targets, r_hw)
+    fm = torch.rand(n_targets * r_hw ** 2, fm_h, fm_w).double().cuda().requires_grad_(True)
+    rois = (torch.Tensor([[0.5, 0.5, 0.1, 0.1], [0.1, 0.1, 0.2, 0.3], [1.5, 1.5, 0.2, 0.2]])
+            .double().cuda().requires_grad_(False))
+    assert gradcheck(pr, (fm, rois))
+
+
+@pytest.mark.parametrize("n_targets", [1, 2])
+@pytest.mark.parametrize("r_hw", [6, 7])
+@pytest.mark.parametrize("fm_h", [10, 11])
+@pytest.mark.parametrize("fm_w", [10, 11])
+def test_ps_roipool_can_handle_oob(n_targets, r_hw, fm_h, fm_w):
+    # torch.full(shape, 10) is int64 on modern torch (float on the reference's torch 1.1): use 10.0
+    from detect_to_track.models import PSROIPool
+    pr = PSROIPool(n_targets, r_hw).cuda()
+    fm = torch.full((n_targets * r_hw ** 2, fm_h, fm_w), 10.0).cuda()
+    rois = torch.as_tensor([[3.0, 3.0, 0.5, 0.5]]).cuda()
+    ans = pr(fm, rois).cpu()
+    assert torch.allclose(ans, torch.zeros(len(rois), n_targets, r_hw, r_hw))
+
+
+def _check_bounds(bounds, ref_bounds):
+    empty = (ref_bounds[..., 0] < 0)
+    ours_empty = (bounds[..., 1] <= bounds[..., 0]) | (bounds[..., 3] <= bounds[..., 2])
+    np.testing.assert_array_equal(ours_empty, empty)
+    np.testing.assert_array_equal(bounds[~empty], ref_bounds[~empty])
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("psroipool") if "known_answer" not in p.stem],
+                         ids=[i for i in golden_ids("psroipool") if "known_answer" not in i])
+def test_matches_reference_fixture(path):
+    from detect_to_track.models import _ext
+    g = load_golden(path)
+    nT, k = int(g["nT"]), int(g["k"])
+    _, H, W = g["fm"].shape
+    tol = TOL32 if g["fm"].dtype == np.float32 else TOL64
+    out = _n(_ext.ps_roipool_forward(_t(g["fm"]), _t(g["rois"]), nT, k))
+    np.testing.assert_array_equal(out, g["out"])                               # bit-exact forward
+    gin = _n(_ext.ps_roipool_backward(_t(g["gout"]), _t(g["rois"]), H, W))
+    np.testing.assert_allclose(gin, g["gin"], **tol)
+    _check_bounds(_n(_ext.roipool_bins(_t(g["rois"]), H, W, k, position_sensitive=True)), g["bounds"])
+    np.testing.assert_array_equal(_n(_ext.ps_roipool_channels(nT, k, DEV)), g["channels"])
+
+
+def test_known_answer_fixture():
+    from detect_to_track.models import _ext
+    g = load_golden([p for p in golden_files("psroipool") if "known_answer" in p.stem][0])
+    fm = torch.full((2 * 49, 10, 11), 10.0, device=DEV)
+    out = _ext.ps_roipool_forward(fm, torch.tensor([[3.0, 3.0, 0.5, 0.5]], device=DEV), 2, 7)
+    np.testing.assert_array_equal(_n(out), g["out"])
+    assert not g["out"].any()
+
+
+CASES = [  # (R, nT, H, W, k)
+    (3, 1, 10, 10, 6), (11, 3, 38, 63, 7), (11, 5, 9, 14, 3), (24, 4, 38, 75, 7), (300, 21, 38, 63, 7),
+    (64, 31, 38, 75, 7), (5, 2, 11, 10, 7), (1, 1, 3, 3, 1), (130, 4, 20, 20, 5),
+]
+
+
+@pytest.mark.parametrize("impl", [0, 1], ids=["auto", "generic"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case", CASES, ids=str)
+def test_matches_oracle(case, dtype, impl, oracle):
+    from detect_to_track.models import _ext
+    R, nT, H, W, k = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    rois = (np.asarray(ADVERSARIAL_ROIS, dtype=dtype) if R == 11 else random_rois(R, R + nT, dtype))
+    fm = rng.random((nT * k * k, H, W)).astype(dtype)
+    gout = rng.random((R, nT, k, k)).astype(dtype)
+    tol = TOL32 if dtype == np.float32 else TOL64
+    out = _n(_ext.ps_roipool_forward(_t(fm), _t(rois), nT, k, impl))
+    np.testing.assert_array_equal(out, oracle.psroipool_fwd(fm, rois, nT, k))
+    gin = _n(_ext.ps_roipool_backward(_t(gout), _t(rois), H, W, impl))
+    np.testing.assert_allclose(gin, oracle.psroipool_bwd(gout, rois, H, W), **tol)
+    np.testing.assert_array_equal(_n(_ext.roipool_bins(_t(rois), H, W, k, position_sensitive=True)),
+                                  oracle.roipool_bins(rois, H, W, k, position_sensitive=True))
+    np.testing.assert_array_equal(_n(_ext.ps_roipool_channels(nT, k, DEV)), oracle.psroipool_channels(nT, k))
+
+
+@pytest.mark.parametrize("case", [(300, 21, 38, 63, 7), (3000, 31, 38, 75, 7), (3000, 4, 38, 75, 7), (11, 3, 38, 63, 7)],
+                         ids=str)
+def test_matches_live_reference(case, ref_modules):
+    from detect_to_track.models import _ext
+    ref_ps = ref_modules[2]
+    R, nT, H, W, k = case
+    torch.manual_seed(7)
+    fm = torch.rand(nT * k * k, H, W, device=DEV)
+    rois = _t(np.asarray(ADVERSARIAL_ROIS, np.float32) if R == 11 else random_rois(R, 1))
+    gout = torch.rand(R, nT, k, k, device=DEV)
+    out = _ext.ps_roipool_forward(fm, rois, nT, k)
+    assert torch.equal(out, ref_ps.ps_roipool_forward(fm, rois, nT, k))
+    gin = _ext.ps_roipool_backward(gout, rois, H, W)
+    # channel 0 collects R*nT contributions per pixel: allow fp32 reordering noise relative to that sum
+    torch.testing.assert_close(gin, ref_ps.ps_roipool_backward(gout, rois, H, W), rtol=2e-5, atol=1e-5)
+    assert torch.equal(gin, _ext.ps_roipool_backward(gout, rois, H, W))        # deterministic
+
+
+def test_channel_collisions_and_unused_channels():
+    """(t+1)*(i*k+j) is many-to-one (reference ps_roipool_cuda.cu:58): for nT=2,k=3 only 13 of 18
+    channels are ever read; the gradient of the other 5 must be exactly zero."""
+    from detect_to_track.models import _ext
+    nT, k, H, W = 2, 3, 12, 12
+    ch = _n(_ext.ps_roipool_channels(nT, k, DEV))
+    used = sorted(set(ch.ravel().tolist()))
+    assert len(used) == 13
+    gout = torch.ones(4, nT, k, k, device=DEV)
+    gin = _ext.ps_roipool_backward(gout, _t(random_rois(4, 3)), H, W)
+    unused = [c for c in range(nT * k * k) if c not in used]
+    assert not gin[unused].any()
+    assert gin[0].sum() > 0      # bin 0 of every target reads channel 0
+
+
+def test_empty_and_errors():
+    from detect_to_track.models import PSROIPool
+    pr = PSROIPool(2, 3)
+    out = pr(torch.rand(18, 10, 10, device=DEV), torch.empty(0, 4, device=DEV))
+    assert out.shape == (0, 2, 3, 3)
+    with pytest.raises(ValueError):
+        pr(torch.rand(17, 10, 10, device=DEV), torch.rand(1, 4, device=DEV))
+    with pytest.raises(RuntimeError, match="CPU op not implemented"):
+        pr(torch.rand(18, 10, 10), torch.rand(1, 4))
