@@ -9,6 +9,14 @@ import os
 from ctypes import c_char_p, c_int, c_size_t, c_void_p
 from pathlib import Path
 
+# torch MUST be imported before libd2t_ops.so is mapped.  The PyTorch-ROCm wheel bundles its own
+# HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7); once it is loaded the dynamic
+# linker resolves our DT_NEEDED libamdhip64.so.7 to that same object, so kernels, streams and
+# device pointers live in ONE runtime.  Loaded the other way round, the system copy under
+# /opt/rocm would be mapped first and torch would add a second runtime next to it: launches from
+# this library then fail with hipErrorNoDevice (seen on the MI355X box).
+import torch  # noqa: F401
+
 _HERE = Path(__file__).resolve().parent
 _LIB_ENV = "D2T_OPS_LIBRARY"
 _DEFAULT = _HERE.parent.parent / "lib" / "libd2t_ops.so"

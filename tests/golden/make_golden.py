@@ -153,7 +153,7 @@ def main():
     for name, (B, C, H, W, d, s) in {
         "d8_c16_12x20": (1, 16, 12, 20, 8, 1), "d8_c16_12x20_s3": (1, 16, 12, 20, 8, 3),
         "d1_c5_7x9": (2, 5, 7, 9, 1, 1), "d0_c3_4x5": (1, 3, 4, 5, 0, 1),
-        "d8_c64_19x23": (2, 64, 19, 23, 8, 1), "d4_c8_5x3": (1, 8, 5, 3, 4, 1),
+        "d8_c24_13x17": (1, 24, 13, 17, 8, 1), "d4_c8_5x3": (1, 8, 5, 3, 4, 1),
         "d2_c7_9x9_s5": (1, 7, 9, 9, 2, 5),
     }.items():
         for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
@@ -185,13 +185,15 @@ def main():
                     for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
                         seed += 1
                         psroipool_case(f"t_n{nT}_k{k}_{H}x{W}_{tag}", nT, H, W, k, ps_rois, dt, seed, out_dir)
+    seed += 1
+    psroipool_case("adv_n1_k7_38x63_f32", 1, 38, 63, 7, ADVERSARIAL_ROIS, np.float32, seed, out_dir)
     for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
         seed += 1
-        psroipool_case(f"adv_n3_k7_38x63_{tag}", 3, 38, 63, 7, ADVERSARIAL_ROIS, dt, seed, out_dir)
+        psroipool_case(f"adv_n3_k7_19x31_{tag}", 3, 19, 31, 7, ADVERSARIAL_ROIS, dt, seed, out_dir)
         seed += 1
         psroipool_case(f"adv_n5_k3_9x14_{tag}", 5, 9, 14, 3, ADVERSARIAL_ROIS, dt, seed, out_dir)
         seed += 1
-        psroipool_case(f"rand_n4_k7_38x75_{tag}", 4, 38, 75, 7, random_rois(24, seed, dt), dt, seed, out_dir)
+        psroipool_case(f"rand_n2_k7_19x25_{tag}", 2, 19, 25, 7, random_rois(24, seed, dt), dt, seed, out_dir)
     # the known-answer case: constant 10 map, RoI (3,3,.5,.5) -> zeros
     fm = np.full((2 * 49, 10, 11), 10.0, dtype=np.float32)
     koa = n(ref_ps.ps_roipool_forward(t(fm), t(np.asarray([[3.0, 3.0, 0.5, 0.5]], np.float32)), 2, 7))
