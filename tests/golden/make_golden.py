@@ -158,6 +158,8 @@ def main():
     }.items():
         for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
             seed += 1
+            if tag == "f64" and C >= 16:            # keep the fixture set small: larger cases f32 only
+                continue
             corr_case(f"{name}_{tag}", B, C, H, W, d, s, dt, seed, out_dir)
 
     # reference tests/test_roipool.py:10-23
@@ -174,7 +176,8 @@ def main():
         seed += 1
         roipool_case(f"adv_k3_c2_9x14_{tag}", 2, 9, 14, 3, ADVERSARIAL_ROIS, dt, seed, out_dir)
         seed += 1
-        roipool_case(f"rand_k7_c8_38x63_{tag}", 8, 38, 63, 7, random_rois(24, seed, dt), dt, seed, out_dir)
+        if tag == "f32":
+            roipool_case(f"rand_k7_c8_38x63_{tag}", 8, 38, 63, 7, random_rois(24, seed, dt), dt, seed, out_dir)
 
     # reference tests/test_ps_roipool.py:8-26 and :33-40
     ps_rois = [[0.5, 0.5, 0.1, 0.1], [0.1, 0.1, 0.2, 0.3], [1.5, 1.5, 0.2, 0.2]]
