@@ -1,0 +1,70 @@
+"""CPU: pin the oracle against the golden fixtures produced by the reference's own kernels
+(tests/golden/make_golden.py, run on MI355X with oracle/_ref).
+
+Bit-exact: correlation forward and gradFM0 (both thread-owned FMA chains in the reference),
+PSROIPool forward (same running-sum order), the written-cell mask, bin/cell bounds, channel map.
+Tolerance: gradients the reference accumulates with atomicAdd (order undefined there): 1e-5 f32,
+1e-12 f64; ROIPool forward: bit-exact as well (same running-sum order, unguarded divide).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_files, golden_ids, load_golden
+
+
+def _tol(dtype):
+    return dict(rtol=1e-5, atol=1e-5) if dtype == np.float32 else dict(rtol=1e-12, atol=1e-12)
+
+
+def test_fixtures_present():
+    assert len(golden_files("corr")) >= 20 and len(golden_files("roipool")) >= 20 and len(golden_files("psroipool")) >= 30
+
+
+@pytest.mark.parametrize("path", golden_files("corr"), ids=golden_ids("corr"))
+def test_correlation(path, oracle):
+    g = load_golden(path)
+    d, s = int(g["d"]), int(g["s"])
+    np.testing.assert_array_equal(oracle.corr_fwd(g["fm0"], g["fm1"], d, s), g["out"])
+    g0, g1 = oracle.corr_bwd(g["gout"], g["fm0"], g["fm1"], d, s)
+    np.testing.assert_array_equal(g0, g["g0"])
+    np.testing.assert_allclose(g1, g["g1"], **_tol(g["fm0"].dtype))
+    H, W = g["fm0"].shape[2:]
+    np.testing.assert_array_equal(oracle.corr_mask(H, W, d, s), g["mask"])
+
+
+def _check_bounds(bounds, ref_bounds):
+    empty = ref_bounds[..., 0] < 0
+    ours_empty = (bounds[..., 1] <= bounds[..., 0]) | (bounds[..., 3] <= bounds[..., 2])
+    np.testing.assert_array_equal(ours_empty, empty)
+    np.testing.assert_array_equal(bounds[~empty], ref_bounds[~empty])
+
+
+@pytest.mark.parametrize("path", golden_files("roipool"), ids=golden_ids("roipool"))
+def test_roipool(path, oracle):
+    g = load_golden(path)
+    k = int(g["k"])
+    _, H, W = g["fm"].shape
+    np.testing.assert_array_equal(oracle.roipool_fwd(g["fm"], g["rois"], k), g["out"])     # NaNs compare equal
+    np.testing.assert_allclose(oracle.roipool_bwd(g["gout"], g["rois"], H, W), g["gin"], **_tol(g["fm"].dtype))
+    _check_bounds(oracle.roipool_bins(g["rois"], H, W, k), g["bounds"])
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("psroipool") if "known_answer" not in p.stem],
+                         ids=[i for i in golden_ids("psroipool") if "known_answer" not in i])
+def test_psroipool(path, oracle):
+    g = load_golden(path)
+    nT, k = int(g["nT"]), int(g["k"])
+    _, H, W = g["fm"].shape
+    np.testing.assert_array_equal(oracle.psroipool_fwd(g["fm"], g["rois"], nT, k), g["out"])
+    np.testing.assert_allclose(oracle.psroipool_bwd(g["gout"], g["rois"], H, W), g["gin"], **_tol(g["fm"].dtype))
+    _check_bounds(oracle.roipool_bins(g["rois"], H, W, k, position_sensitive=True), g["bounds"])
+    np.testing.assert_array_equal(oracle.psroipool_channels(nT, k), g["channels"])
+
+
+def test_psroipool_known_answer(oracle):
+    """reference tests/test_ps_roipool.py:33-44: constant map, RoI (3,3,.5,.5) -> all zeros."""
+    g = load_golden([p for p in golden_files("psroipool") if "known_answer" in p.stem][0])
+    fm = np.full((2 * 49, 10, 11), 10.0, dtype=np.float32)
+    out = oracle.psroipool_fwd(fm, np.asarray([[3.0, 3.0, 0.5, 0.5]], np.float32), 2, 7)
+    np.testing.assert_array_equal(out, g["out"])
+    assert not out.any()
