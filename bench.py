@@ -97,6 +97,28 @@ def cpu_baseline(cfg, counts, budget_s=12.0):
                        f"oracle/libd2t_oracle.so with OpenMP over {threads} threads")
 
 
+def rank_env():
+    """(rank, world, local_rank) as torch.distributed.run exports them; (0, 1, 0) when launched bare."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def max_over_ranks(seconds, world, device=None):
+    """The timed region ends when the slowest rank is done: MAX over ranks of the elapsed time."""
+    if world == 1:
+        return seconds
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_value(units_per_rank_step, world, steps, elapsed_s):
+    """Aggregate throughput: every rank processes its own shard (weak scaling, no exchange)."""
+    return world * units_per_rank_step * steps / elapsed_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,9 +134,7 @@ def main():
     import torch.distributed as dist
     from detect_to_track.models import _native           # raises ImportError if the HIP library is missing
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = rank_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
@@ -184,14 +204,11 @@ def main():
 
     t_fwd = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K)) / K * 1e-3      # s per launch
     t_bwd = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)) / K * 1e-3
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, world, dev)
 
     if rank == 0:
         ms = elapsed / K * 1e3
-        value = world * cnt["vox"] * K / elapsed / 1e9
+        value = whole_job_value(cnt["vox"], world, K, elapsed) / 1e9
 
         def roof(name, t, nbytes, flops):
             return dict(kernel=name, us=t * 1e6,

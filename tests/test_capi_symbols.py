@@ -1,0 +1,71 @@
+"""CPU: the C-ABI library loads, exports every symbol include/d2t_ops.h declares, and rejects bad
+arguments with the documented codes BEFORE touching a device (no compute without a GPU)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = (ROOT / "include" / "d2t_ops.h").read_text()
+
+
+def declared_functions():
+    names = re.findall(r"^\s*(?:int|size_t|const char\*)\s+(d2t_\w+)\s*\(", HEADER, flags=re.M)
+    assert len(names) >= 26
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from detect_to_track.models import _native
+    return _native
+
+
+@pytest.mark.parametrize("name", declared_functions())
+def test_symbol_exported(name, native):
+    assert hasattr(native.lib, name), f"{name} declared in include/d2t_ops.h but not exported"
+    assert name in native.SYMBOLS, f"{name} has no ctypes prototype in _native.py"
+
+
+def test_version_and_error_strings(native):
+    assert native.version() >= 100
+    assert native.error_string(0) == b"ok"
+    for code in (-1, -2, -3):
+        assert native.error_string(code) and native.error_string(code) != b"ok"
+
+
+def test_argument_validation_without_device(native):
+    L = native.lib
+    EINVAL, ETOOBIG, EWS = -1, -2, -3
+    # null pointers with non-empty extents
+    assert L.d2t_corr_fwd_f32(None, None, None, 1, 2, 5, 5, 2, 1, None, 0, 0, None) == EINVAL
+    # stride < 1, negative extent
+    assert L.d2t_corr_fwd_f32(8, 8, 8, 1, 2, 5, 5, 2, 0, None, 0, 0, None) == EINVAL
+    assert L.d2t_corr_fwd_f64(8, 8, 8, -1, 2, 5, 5, 2, 1, None, 0, 0, None) == EINVAL
+    # output element count beyond int32 (reference offsets are int: pointwise_correlation_cuda.cu:44-50)
+    assert L.d2t_corr_fwd_f32(8, 8, 8, 64, 2, 512, 512, 8, 1, None, 0, 0, None) == ETOOBIG
+    assert L.d2t_roipool_fwd_f32(8, 8, 8, 300000, 1024, 38, 63, 7, None, 0, 0, None) == ETOOBIG
+    # k < 1
+    assert L.d2t_roipool_fwd_f32(8, 8, 8, 1, 1, 5, 5, 0, None, 0, 0, None) == EINVAL
+    assert L.d2t_psroipool_fwd_f64(8, 8, 8, 1, 1, 5, 5, 0, None, 0, 0, None) == EINVAL
+    # backward needs its bin-table workspace
+    assert L.d2t_roipool_bwd_f64(8, 8, 8, 3, 2, 10, 10, 5, None, 0, 1, None) == EWS
+    assert L.d2t_psroipool_bwd_f64(8, 8, 8, 3, 2, 10, 10, 5, None, 0, 1, None) == EWS
+    need = L.d2t_roipool_bwd_workspace_bytes(3, 2, 10, 10, 5, 8)
+    assert need >= 3 * 5 * 5 * 4 * 4
+    assert L.d2t_psroipool_bwd_workspace_bytes(3, 2, 10, 10, 5, 8) >= 3 * 5 * 5 * 4 * 4
+    # the tuned-only selector refuses shapes the tuned kernels do not take instead of silently falling back
+    assert L.d2t_corr_fwd_f32(8, 8, 8, 1, 2, 10, 10, 3, 1, None, 0, 2, None) == EINVAL
+    assert L.d2t_corr_fwd_f64(8, 8, 8, 1, 2, 38, 63, 8, 1, None, 0, 2, None) == EINVAL
+    # introspection entry points validate too
+    assert L.d2t_corr_mask(None, 5, 5, 2, 1, None) == EINVAL
+    assert L.d2t_psroipool_channels(None, 2, 3, None) == EINVAL
+    assert L.d2t_roipool_bins_f32(None, None, 2, 5, 5, 3, None) == EINVAL
+
+
+def test_header_cites_the_reference_binding():
+    # every replaced pybind function is named with its file:line
+    for token in ("pointwise_correlation.cpp:23-33", "pointwise_correlation.cpp:36-48", "roipool.cpp:22-32",
+                  "roipool.cpp:35-45", "ps_roipool.cpp:23-34", "ps_roipool.cpp:37-47"):
+        assert token in HEADER

@@ -1,0 +1,78 @@
+"""CPU, world_size 2, gloo: the multi-GPU path of bench.py.
+
+The hot path shards by frame pair with NO exchange step: a rank's outputs
+depend only on its own shard.  The only cross-rank operations in bench.py are the timing barrier
+and the MAX-over-ranks reduction; both are exercised here over gloo, together with the
+shard-independence property itself (checked with the CPU oracle: test infrastructure).
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), OMP_NUM_THREADS="2")
+    sys.path[:0] = [str(ROOT), str(ROOT / "oracle"), str(ROOT / "detect-to-track_amd")]
+    import bench
+    import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert bench.rank_env() == (rank, world, rank)
+        # (1) MAX over ranks of the elapsed time: rank r "takes" 1 + r seconds
+        elapsed = bench.max_over_ranks(1.0 + rank, world)
+        assert elapsed == float(world)
+        # (2) whole-job value counts every rank's shard once
+        assert bench.whole_job_value(100, world, 10, elapsed) == world * 100 * 10 / elapsed
+        # (3) shard independence: each rank runs the oracle on ITS pairs only; gathered, the result
+        #     equals the full-batch computation bit for bit -> no data-path collective is needed
+        rng = np.random.default_rng(7)
+        B, C, H, W, d = 4, 6, 9, 21, 8
+        fm0, fm1 = rng.random((B, C, H, W), dtype=np.float32), rng.random((B, C, H, W), dtype=np.float32)
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        mine = torch.from_numpy(O.corr_fwd(fm0[lo:hi], fm1[lo:hi], d, 1))
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)                       # test-side gather only, to compare
+        full = O.corr_fwd(fm0, fm1, d, 1)
+        assert np.array_equal(torch.cat(parts).numpy(), full)
+        dist.barrier()
+        q.put((rank, "ok"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == [0, 1]
+
+
+def test_corr_counts_match_baseline_md():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    c = bench.corr_counts(**bench.WORKLOADS["corr_B8_C256_38x63_d8"])
+    assert c["vox"] == 5534928 and c["fwd_bytes"] == 61363008 and c["bwd_bytes"] == 100586304
+    assert c["fwd_flops"] == 2103443456 and c["bwd_flops"] == 2 * 2103443456
