@@ -190,136 +190,166 @@ int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, i
 // ====================================================================================
 // Backward.  Both gradients have the same shape of work:
 //     gX[c][t] = sum over window slots w of  G[t][w] * S[c][w]
-// role 0 (gradFM0): t = the 16 pixels (i,j) of a 4x4 tile, S = FM1, the window is the union of
-//                   their displacement windows, G[t][w] = gradOut[b,i,j,di-i+d,dj-j+d];
-// role 1 (gradFM1): t = the 16 displaced pixels (di,dj) of a 4x4 tile, S = FM0, the window is
-//                   the set of centres (i,j) that reach them (rows di0-d+1 .. di0+3+d), same G.
+// role 0 (gradFM0): t = centre pixels (i,j), S = FM1, slots = the displaced pixels they reach;
+// role 1 (gradFM1): t = displaced pixels (di,dj), S = FM0, slots = the centres that reach them;
+// in both, G = gradOut[b,i,j,di-i+d,dj-j+d] where the reference's loops visit that cell, else 0.
 // This is the gather form of pointwise_correlation_cuda.cu:154-171: no atomics, every output
-// element written once, summation order fixed (deterministic).
+// element written exactly once, fixed summation order (bitwise reproducible).
 //
-// MFMA mapping: D[m = 16 channels][n = 16 tile pixels] += A[m][k] * B[k][n], k = window slots,
-// 4 per MFMA.  The window is enumerated exactly as in the forward (rows inside the map only,
-// 5 groups of 4 columns, column origin clamped into the map).  One lane owns channel m and
-// k-slot g: ONE 16-byte load of group gamma = 4*kb + g gives its A operand for the four
-// MFMAs of k-block kb (MFMA s of the block uses column s of every lane's group), and one
-// ds_read_b128 of the G tile ([gamma][t][s] in LDS) gives the matching B operands.  Slots that
-// are padding (gamma >= NG, the 20th column, cells outside a pixel's own window) have G = 0.
-// A wave owns 4 c-tiles (64 channels) at a time: 4 loads + 1 LDS read feed 16 MFMAs.
+// Column-strip kernel.  One workgroup owns (role, batch item, a strip 4 pixels wide, 256
+// channels) and walks the strip top to bottom.  The strip's slots are the map rows x 20 columns
+// (5 groups of 4, origin clamped into the map); 4 groups = one k-block = 16 MFMA k-slots, 5
+// k-blocks = one "super-step" = 4 map rows = one tile pitch.  A 4x4 tile u of output pixels
+// interacts with super-steps u-2 .. u+2, so at any time 5 tiles are alive.
+//   MFMA: D[m = 16 channels][n = 16 tile pixels] += A[m][k] * B[k][n].
+//   A: lane (channel m, k-slot g) loads ONE 16-byte piece of S per k-block (group 4*kb+g); its
+//      4 floats are the A operands of the block's 4 MFMAs -- and of all 5 live tiles, so every
+//      byte of S is fetched once per strip instead of once per tile (~5x less L2 traffic than a
+//      tile-per-workgroup layout, which measured L2-bound).
+//   B: G fragments [k-block][live tile][lane][4] of a whole super-step are produced cooperatively
+//      (6-7 elements per thread, read straight from gradOut, zero where the reference's loops do
+//      not go) into a double-buffered LDS ring, one workgroup barrier per super-step; each wave
+//      reads them back with ds_read_b128.  Waves drift apart inside a super-step, so one wave's
+//      index arithmetic overlaps another wave's MFMAs.
+// A wave owns one c-tile (16 channels): 1 load + 5 LDS reads feed 20 MFMAs per k-block; 16 waves
+// share the ring.  After super-step s tile s-2 is complete: it is stored and the 5 accumulators
+// rotate.  At B=8, C=256, 38x63 the grid is 2 x 8 x 16 = 256 workgroups: one per CU.
 // ====================================================================================
-constexpr int BWD_WAVES = 4;
-constexpr int BWD_THREADS = BWD_WAVES * 64;
-constexpr int NGMAX = WR * NCG;                     // 95
-constexpr int NKB = (NGMAX + 3) / 4;                // 24 k-blocks of 16 slots
-constexpr int GT_FLOATS = NKB * 4 * 64;             // G tile [96 groups][16 t][4 s]
+constexpr int ST_WAVES = 16;
+constexpr int ST_THREADS = ST_WAVES * 64;
+constexpr int ST_CH = ST_WAVES * 16;                // channels per workgroup pass
+constexpr int NACT = 5;                             // tiles alive during one super-step
+constexpr int KB_SS = 5;                            // k-blocks per super-step
+constexpr int RING = NACT * 256;                    // floats of G per k-block: [tile][lane][4]
+constexpr int RING_SS = KB_SS * RING;               // per super-step: 6400 floats = 25 KB
+constexpr int G_PER_THREAD = (RING_SS + ST_THREADS - 1) / ST_THREADS;   // 7
 
-__global__ void __launch_bounds__(BWD_THREADS)
-k_corr_bwd_mfma(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
-                float* __restrict__ g0, float* __restrict__ g1,
-                int C, int H, int W, int tiles_i, int tiles_j, int tiles_total)
+// One element of the G ring for k-block kb = 5*ss + q: e = (live tile a, lane l, column s).
+// The cell index inside a gradOut row depends only on (q, e); the row itself advances by 4 map
+// rows per super-step.
+__device__ __forceinline__ float strip_g(const float* __restrict__ gb, int role, int ss, int q, int e,
+                                         int H, int W, int tiles_i, int j0, int col0)
 {
-    __shared__ __attribute__((aligned(16))) float gs[GT_FLOATS];      // 24 KB
+    const int a = e >> 8, l = (e >> 2) & 63, s = e & 3, t = l & 15, gg = l >> 4;
+    const int u = ss - 2 + a;                                       // tile row
+    const int x = 4 * q + gg, xr = (x * 13) >> 6, cg = x - xr * NCG; // x / 5, x % 5 for x in 0..19
+    const int rho = 4 * ss + xr;                                    // slot row
+    const int ti = 4 * u + (t >> 2), tj = j0 + (t & 3);             // tile pixel
+    const int sj = col0 + 4 * cg + s;                               // slot column (always in the map)
+    const int ci = role ? ti - rho + DT : rho - ti + DT;            // displaced - centre + d
+    const int cj = role ? tj - sj + DT : sj - tj + DT;
+    const bool ok = u >= 0 && u < tiles_i && ti < H && tj < W && rho < H &&
+                    ci >= 0 && ci < 2 * DT && cj >= 0 && cj < 2 * DT;
+    const int pix = role ? rho * W + sj : ti * W + tj;              // centre pixel
+    return ok ? gb[(size_t)pix * CELLS + ci * CW + cj] : 0.f;
+}
+
+__global__ void __launch_bounds__(ST_THREADS)
+k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
+                 float* __restrict__ g0, float* __restrict__ g1,
+                 int B, int C, int H, int W, int tiles_i, int tiles_j)
+{
+    __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 50 KB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int role = bid >= tiles_total ? 1 : 0;                      // first all gradFM0 tiles, then gradFM1
-    bid -= role * tiles_total;
-    const int tj = bid % tiles_j, ti = (bid / tiles_j) % tiles_i, b = bid / (tiles_j * tiles_i);
-    const int i0 = ti * TP, j0 = tj * TP, HW = H * W;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // (role, b) pairs stay on one XCD
+    const int tj = bid % tiles_j, b = (bid / tiles_j) % B, role = bid / (tiles_j * B);
+    const int j0 = tj * TP, HW = H * W;
+    const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
+    const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
     const float* S = role ? fm0 : fm1;
     float* gx = role ? g1 : g0;
-
-    // window geometry: role 0 rows i0-d .. i0+3+d-1, role 1 rows i0-d+1 .. i0+3+d (same for columns)
-    const int wtop = i0 - DT + role, wleft = j0 - DT + role;
-    const int row_first = wtop > 0 ? wtop : 0;
-    const int row_end = wtop + WR < H ? wtop + WR : H;                // exclusive
-    const int NG = (row_end - row_first) * NCG;
-    const int nkb = (NG + 3) >> 2;
-    const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
-
-    // ---- build the G tile in LDS: gs[(gamma*16 + t)*4 + s] ----
     const float* gb = gout + (size_t)b * HW * CELLS;
-    if (role == 0) {
-        for (int e = tid; e < GT_FLOATS; e += BWD_THREADS) gs[e] = 0.f;
-        __syncthreads();
-        for (int e = tid; e < 16 * CELLS; e += BWD_THREADS) {
-            const int t = e / CELLS, cell = e - t * CELLS;
-            const int ci = cell / CW, cj = cell - ci * CW;
-            const int i = i0 + (t >> 2), j = j0 + (t & 3);
-            const int di = i + ci - DT, dj = j + cj - DT;
-            if (ci < 2 * DT && cj < 2 * DT && i < H && j < W && di >= 0 && di < H && dj >= 0 && dj < W) {
-                const int wcc = dj - col0;                            // 0..19 by construction
-                const int gamma = (di - row_first) * NCG + (wcc >> 2);
-                gs[(gamma * 16 + t) * 4 + (wcc & 3)] = gb[(size_t)(i * W + j) * CELLS + cell];
-            }
+
+    const int cw = blockIdx.y * ST_CH + wave * 16;                   // first channel of this wave's c-tile
+    const bool wave_on = cw < C;
+    const int cl = cw + n < C ? cw + n : C - 1;                      // lane's channel (clamped; never stored)
+    const float* sp = S + ((size_t)b * C + cl) * HW + col0;
+
+    f32x4 acc[NACT];
+#pragma unroll
+    for (int a = 0; a < NACT; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto s_load = [&](int kb) -> f32x4 {
+        const int gamma = 4 * kb + g;
+        int rho = gamma / NCG;
+        const int cg = gamma - rho * NCG;
+        rho = rho < H ? rho : H - 1;                                 // rows past the map carry G = 0
+        return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
+    };
+    auto store_tile = [&](const f32x4& d, int u) {
+        const int i = 4 * u + (n >> 2), j = j0 + (n & 3);
+        if (u < 0 || u >= tiles_i || !wave_on || i >= H || j >= W) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = cw + 4 * g + r;
+            if (c < C) gx[((size_t)b * C + c) * HW + i * W + j] = d[r];
         }
-    } else {
-        for (int e = tid; e < GT_FLOATS; e += BWD_THREADS) {
-            const int s = e & 3, t = (e >> 2) & 15, gamma = e >> 6;
-            float v = 0.f;
-            if (gamma < NG) {
-                const int er = gamma / NCG, cg = gamma - er * NCG;
-                const int i = row_first + er, j = col0 + 4 * cg + s;   // centre pixel, inside the map
-                const int di = i0 + (t >> 2), dj = j0 + (t & 3);
-                const int ci = di - i + DT, cj = dj - j + DT;
-                if (ci >= 0 && ci < 2 * DT && cj >= 0 && cj < 2 * DT && di < H && dj < W)
-                    v = gb[(size_t)(i * W + j) * CELLS + ci * CW + cj];
-            }
-            gs[e] = v;
-        }
-    }
+    };
+    // element k of this thread in a super-step's ring: index tid + k*1024 = (q, e)
+    auto g_elem = [&](int ss, int k) -> float {
+        const int e5 = tid + k * ST_THREADS;
+        if (e5 >= RING_SS) return 0.f;
+        const int q = e5 / RING;
+        return strip_g(gb, role, ss, q, e5 - q * RING, H, W, tiles_i, j0, col0);
+    };
+
+    // prologue: ring[0] <- super-step 0
+#pragma unroll
+    for (int k = 0; k < G_PER_THREAD; ++k)
+        if (tid + k * ST_THREADS < RING_SS) ring[0][tid + k * ST_THREADS] = g_elem(0, k);
+    f32x4 av = wave_on ? s_load(0) : f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    // ---- main loop: passes of 64 channels per wave (4 c-tiles), 256 per workgroup ----
-    const f32x4* gs4 = reinterpret_cast<const f32x4*>(gs);
-    const int tpi = n >> 2, tpj = n & 3;                              // tile pixel of output column n
-    const bool pix_ok = i0 + tpi < H && j0 + tpj < W;
-    for (int cbase = wave * 64; cbase < C; cbase += BWD_WAVES * 64) {
-        // lane's channel in each of the 4 c-tiles (clamped: rows past C are never stored)
-        const float* sp[4];
+    for (int ss = 0; ss < tiles_i; ++ss) {
+        const int cur = ss & 1;
+        // request the next super-step's G now; it is written to the other buffer after this
+        // super-step's 100 MFMAs, so the loads' latency hides behind them
+        float gn[G_PER_THREAD];
+        const bool more = ss + 1 < tiles_i;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int c = cbase + 16 * u + n;
-            c = c < C ? c : C - 1;
-            sp[u] = S + ((size_t)b * C + c) * HW + row_first * W + col0;
-        }
-        f32x4 acc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < G_PER_THREAD; ++k) gn[k] = more ? g_elem(ss + 1, k) : 0.f;
 
-        for (int kb = 0; kb < nkb; ++kb) {
-            int gamma = 4 * kb + g;
-            const f32x4 bv = gs4[gamma * 16 + n];                     // G[t = n][slots of gamma], 0 if gamma >= NG
-            gamma = gamma < NG ? gamma : NG - 1;
-            const int er = gamma / NCG, cg = gamma - er * NCG;
-            const int off = er * W + 4 * cg;
-            f32x4 av[4];
+        if (wave_on) {
+            const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) av[u] = *reinterpret_cast<const f32x4u*>(sp[u] + off);
+            for (int q = 0; q < KB_SS; ++q) {
+                const int kb = ss * KB_SS + q;
+                const f32x4 a4 = av;
+                if (q + 1 < KB_SS || more) av = s_load(kb + 1);
+                f32x4 bv[NACT];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+                for (int a = 0; a < NACT; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
+                // role 0: tile ss-2's window ends a row early, its last k-block is all zeros
+                const int a_lo = (q == KB_SS - 1 && role == 0) ? 1 : 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = D2T_MFMA(av[u][s], bv[s], acc[u]);
-            }
-        }
-        // D[m = 4g + r][n]: channel cbase + 16u + 4g + r, tile pixel n
-        if (pix_ok) {
+                for (int s = 0; s < 4; ++s) {                        // s outer: 5 independent accumulators
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = cbase + 16 * u + 4 * g + r;
-                    if (c < C) gx[((size_t)b * C + c) * HW + (i0 + tpi) * W + j0 + tpj] = acc[u][r];
+                    for (int a = 0; a < NACT; ++a)
+                        if (a >= a_lo) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
                 }
             }
         }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < G_PER_THREAD; ++k)
+                if (tid + k * ST_THREADS < RING_SS) ring[cur ^ 1][tid + k * ST_THREADS] = gn[k];
+        }
+        __syncthreads();
+        store_tile(acc[0], ss - 2);                                  // complete after its 5th super-step
+#pragma unroll
+        for (int a = 0; a + 1 < NACT; ++a) acc[a] = acc[a + 1];
+        acc[NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    store_tile(acc[0], tiles_i - 2);                                 // their remaining super-steps lie below the map
+    store_tile(acc[1], tiles_i - 1);
 }
 
 bool corr_bwd_supported(int B, int C, int H, int W, int d, int s)
 {
     if (d != DT || s != 1 || B < 1 || C < 1 || H < 1 || W < WC) return false;
-    const long long blocks = 2LL * B * ((H + TP - 1) / TP) * ((W + TP - 1) / TP);
-    return blocks <= 0x7fffffffLL;
+    const long long blocks = 2LL * B * ((W + TP - 1) / TP);
+    return blocks <= 0x7fffffffLL && (C + ST_CH - 1) / ST_CH <= 65535;
 }
 
 size_t corr_bwd_ws_bytes(int, int, int, int, int, int) { return 0; }
@@ -328,9 +358,8 @@ int corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g
                  int B, int C, int H, int W, int, int, void*, hipStream_t st)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
-    const int tiles_total = B * tiles_i * tiles_j;
-    hipLaunchKernelGGL(k_corr_bwd_mfma, dim3(2 * tiles_total), dim3(BWD_THREADS), 0, st,
-                       gout, fm0, fm1, g0, g1, C, H, W, tiles_i, tiles_j, tiles_total);
+    hipLaunchKernelGGL(k_corr_bwd_strip, dim3(2 * B * tiles_j, (C + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
+                       gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
     return launch_status();
 }
 
