@@ -221,27 +221,40 @@ constexpr int ST_CH = ST_WAVES * 16;                // channels per workgroup pa
 constexpr int NACT = 5;                             // tiles alive during one super-step
 constexpr int KB_SS = 5;                            // k-blocks per super-step
 constexpr int RING = NACT * 256;                    // floats of G per k-block: [tile][lane][4]
-constexpr int RING_SS = KB_SS * RING;               // per super-step: 6400 floats = 25 KB
-constexpr int G_PER_THREAD = (RING_SS + ST_THREADS - 1) / ST_THREADS;   // 7
+// (1600 of the 2048 quad slots of a super-step are real: 5 k-blocks x 5 tiles x 64 lanes)
+constexpr int Q_PER_THREAD = 2;                     // every thread produces 2 quads: 2048 slots, 448 unused
+constexpr int RING_SS = Q_PER_THREAD * ST_THREADS * 4;   // 8192 floats = 32 KB per buffer
 
-// One element of the G ring for k-block kb = 5*ss + q: e = (live tile a, lane l, column s).
-// The cell index inside a gradOut row depends only on (q, e); the row itself advances by 4 map
-// rows per super-step.
-__device__ __forceinline__ float strip_g(const float* __restrict__ gb, int role, int ss, int q, int e,
-                                         int H, int W, int tiles_i, int j0, int col0)
+// Four consecutive elements (columns s = 0..3) of the G ring for k-block 5*ss + q, live tile a,
+// lane l.  The cell inside a gradOut row depends only on (q, a, l); the row advances by 4 map
+// rows per super-step.  role 0: the four cells are adjacent in one gradOut row; role 1: they sit
+// in four adjacent centre pixels, one cell to the left each time.
+__device__ __forceinline__ f32x4 strip_quad(const float* __restrict__ gb, int role, int ss, int q, int a, int l,
+                                            int H, int W, int tiles_i, int j0, int col0)
 {
-    const int a = e >> 8, l = (e >> 2) & 63, s = e & 3, t = l & 15, gg = l >> 4;
+    const int t = l & 15, gg = l >> 4;
     const int u = ss - 2 + a;                                       // tile row
     const int x = 4 * q + gg, xr = (x * 13) >> 6, cg = x - xr * NCG; // x / 5, x % 5 for x in 0..19
     const int rho = 4 * ss + xr;                                    // slot row
     const int ti = 4 * u + (t >> 2), tj = j0 + (t & 3);             // tile pixel
-    const int sj = col0 + 4 * cg + s;                               // slot column (always in the map)
+    const int sj = col0 + 4 * cg;                                   // first slot column (all 4 in the map)
     const int ci = role ? ti - rho + DT : rho - ti + DT;            // displaced - centre + d
-    const int cj = role ? tj - sj + DT : sj - tj + DT;
-    const bool ok = u >= 0 && u < tiles_i && ti < H && tj < W && rho < H &&
-                    ci >= 0 && ci < 2 * DT && cj >= 0 && cj < 2 * DT;
-    const int pix = role ? rho * W + sj : ti * W + tj;              // centre pixel
-    return ok ? gb[(size_t)pix * CELLS + ci * CW + cj] : 0.f;
+    const int cj = role ? tj - sj + DT : sj - tj + DT;              // for s = 0; role 0: +s, role 1: -s
+    const bool ok = u >= 0 && u < tiles_i && ti < H && tj < W && rho < H && ci >= 0 && ci < 2 * DT;
+    const int pix = role ? rho * W + sj : ti * W + tj;              // centre pixel for s = 0
+    const int off = pix * CELLS + ci * CW + cj;                     // fits int32 (checked by the C ABI)
+    const int dp = role ? CELLS - 1 : 1;                            // next s: next centre & cell-1, or cell+1
+    const int dc = role ? -1 : 1;
+    f32x4 v;
+    // branch-free: an element that is not needed loads gb[0] and is replaced by 0
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = cj + dc * s;
+        const bool use = ok && c >= 0 && c < 2 * DT;
+        const float x_ = gb[use ? off + dp * s : 0];
+        v[s] = use ? x_ : 0.f;
+    }
+    return v;
 }
 
 __global__ void __launch_bounds__(ST_THREADS)
@@ -249,7 +262,7 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
                  float* __restrict__ g0, float* __restrict__ g1,
                  int B, int C, int H, int W, int tiles_i, int tiles_j)
 {
-    __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 50 KB
+    __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 64 KB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);                // (role, b) pairs stay on one XCD
@@ -262,7 +275,6 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
     const float* gb = gout + (size_t)b * HW * CELLS;
 
     const int cw = blockIdx.y * ST_CH + wave * 16;                   // first channel of this wave's c-tile
-    const bool wave_on = cw < C;
     const int cl = cw + n < C ? cw + n : C - 1;                      // lane's channel (clamped; never stored)
     const float* sp = S + ((size_t)b * C + cl) * HW + col0;
 
@@ -270,71 +282,61 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
 #pragma unroll
     for (int a = 0; a < NACT; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto s_load = [&](int kb) -> f32x4 {
-        const int gamma = 4 * kb + g;
-        int rho = gamma / NCG;
-        const int cg = gamma - rho * NCG;
-        rho = rho < H ? rho : H - 1;                                 // rows past the map carry G = 0
+    // S fragment of k-block 5*ss + q: group 20*ss + 4q + g.  Rows past the map carry G = 0.
+    auto s_load = [&](int ss, int q) -> f32x4 {
+        const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
+        int rho = 4 * ss + xr;
+        rho = rho < H ? rho : H - 1;
         return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
     };
     auto store_tile = [&](const f32x4& d, int u) {
         const int i = 4 * u + (n >> 2), j = j0 + (n & 3);
-        if (u < 0 || u >= tiles_i || !wave_on || i >= H || j >= W) return;
+        if (u < 0 || u >= tiles_i || i >= H || j >= W) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = cw + 4 * g + r;
             if (c < C) gx[((size_t)b * C + c) * HW + i * W + j] = d[r];
         }
     };
-    // element k of this thread in a super-step's ring: index tid + k*1024 = (q, e)
-    auto g_elem = [&](int ss, int k) -> float {
-        const int e5 = tid + k * ST_THREADS;
-        if (e5 >= RING_SS) return 0.f;
-        const int q = e5 / RING;
-        return strip_g(gb, role, ss, q, e5 - q * RING, H, W, tiles_i, j0, col0);
+    // quad k of this thread in a super-step's ring: slot tid + k*1024 = (q, a, lane); slots >= 1600
+    // are padding (they decode to q >= 5, rows that belong to the next super-step: never read)
+    auto g_quad = [&](int ss, int k) -> f32x4 {
+        const int e = tid + k * ST_THREADS;
+        const int q = e / (NACT * 64), r = e - q * (NACT * 64);
+        return strip_quad(gb, role, ss, q, r >> 6, r & 63, H, W, tiles_i, j0, col0);
     };
 
     // prologue: ring[0] <- super-step 0
 #pragma unroll
-    for (int k = 0; k < G_PER_THREAD; ++k)
-        if (tid + k * ST_THREADS < RING_SS) ring[0][tid + k * ST_THREADS] = g_elem(0, k);
-    f32x4 av = wave_on ? s_load(0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < Q_PER_THREAD; ++k)
+        reinterpret_cast<f32x4*>(ring[0])[tid + k * ST_THREADS] = g_quad(0, k);
+    f32x4 av = s_load(0, 0);
     __syncthreads();
 
+    // The loop body is straight-line code (no branches): every load is unconditional, so the
+    // compiler can retire them with counted s_waitcnt instead of draining at block boundaries.
     for (int ss = 0; ss < tiles_i; ++ss) {
         const int cur = ss & 1;
-        // request the next super-step's G now; it is written to the other buffer after this
-        // super-step's 100 MFMAs, so the loads' latency hides behind them
-        float gn[G_PER_THREAD];
-        const bool more = ss + 1 < tiles_i;
+        const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
+        f32x4 gn[Q_PER_THREAD];
 #pragma unroll
-        for (int k = 0; k < G_PER_THREAD; ++k) gn[k] = more ? g_elem(ss + 1, k) : 0.f;
-
-        if (wave_on) {
-            const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
+        for (int k = 0; k < Q_PER_THREAD; ++k) gn[k] = g_quad(ss + 1, k);   // past the map: all zeros
 #pragma unroll
-            for (int q = 0; q < KB_SS; ++q) {
-                const int kb = ss * KB_SS + q;
-                const f32x4 a4 = av;
-                if (q + 1 < KB_SS || more) av = s_load(kb + 1);
-                f32x4 bv[NACT];
+        for (int q = 0; q < KB_SS; ++q) {
+            const f32x4 a4 = av;
+            av = q + 1 < KB_SS ? s_load(ss, q + 1) : s_load(ss + 1, 0);
+            f32x4 bv[NACT];
 #pragma unroll
-                for (int a = 0; a < NACT; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
-                // role 0: tile ss-2's window ends a row early, its last k-block is all zeros
-                const int a_lo = (q == KB_SS - 1 && role == 0) ? 1 : 0;
+            for (int a = 0; a < NACT; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {                        // s outer: 5 independent accumulators
+            for (int s = 0; s < 4; ++s) {                            // s outer: 5 independent accumulators
 #pragma unroll
-                    for (int a = 0; a < NACT; ++a)
-                        if (a >= a_lo) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
-                }
+                for (int a = 0; a < NACT; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
             }
         }
-        if (more) {
 #pragma unroll
-            for (int k = 0; k < G_PER_THREAD; ++k)
-                if (tid + k * ST_THREADS < RING_SS) ring[cur ^ 1][tid + k * ST_THREADS] = gn[k];
-        }
+        for (int k = 0; k < Q_PER_THREAD; ++k)
+            reinterpret_cast<f32x4*>(ring[cur ^ 1])[tid + k * ST_THREADS] = gn[k];
         __syncthreads();
         store_tile(acc[0], ss - 2);                                  // complete after its 5th super-step
 #pragma unroll
