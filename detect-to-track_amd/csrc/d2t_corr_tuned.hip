@@ -40,7 +40,6 @@ constexpr int CW = 2 * DT + 1;             // 17
 constexpr int CELLS = CW * CW;             // 289
 constexpr int FWD_WAVES = 6;               // >= max tile-groups = ceil(19*5/16)
 constexpr int FWD_THREADS = FWD_WAVES * 64;
-constexpr int CA = 256;                    // FM0 channels staged in LDS per pass
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of logical tiles
 // (bijective for any grid size).  Placement only affects L2 reuse, never results.
@@ -49,12 +48,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+constexpr int ACH = 64;                    // FM0 channels per staged chunk (16 k-steps)
+
 __global__ void __launch_bounds__(FWD_THREADS, 8)      // 8 waves/SIMD: 5 workgroups (30 waves) per CU
 k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
                 int C, int H, int W, int tiles_i, int tiles_j)
 {
-    __shared__ float smem[16 * CELLS];                 // 18.5 KB: FM0 tile [CA][16], later the out tile
-    static_assert(16 * CELLS >= CA * 16, "out tile must cover the FM0 staging tile");
+    // 18.5 KB: two FM0 chunk buffers [ACH][16] (8 KB) during the main loop, then the out tile
+    __shared__ __attribute__((aligned(16))) float smem[16 * CELLS];
+    static_assert(16 * CELLS >= 2 * ACH * 16, "out tile must cover the FM0 staging buffers");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -76,66 +78,65 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     const int wr = wr_lo + gi / NCG;
     const int di = i0 - DT + wr;
     const int djs = col0 + 4 * (gi % NCG);
-    const int boff = g * HW + di * W + djs;            // lane part of the FM1 address (channel g)
-    const int kstride = 4 * HW;                         // one k-step = 4 channels
+    const float* bp = fm1 + (size_t)b * C * HW + g * HW + di * W + djs;   // channel g of k-step 0
 
-    // FM0 pixel this thread stages (clamped into the map; rows of partial tiles are never stored)
-    const int am = tid & 15;
-    const int ai = i0 + (am >> 2) < H ? i0 + (am >> 2) : H - 1;
-    const int aj = j0 + (am & 3) < W ? j0 + (am & 3) : W - 1;
+    // FM0 staging: threads 0..255 each move one row (4 pixels, 16 bytes) of one channel per chunk.
+    // Pixels of partial tiles are clamped into the map (their outputs are never stored).
+    const int sch = tid >> 2, srow = tid & 3;
+    const int ai = i0 + srow < H ? i0 + srow : H - 1;
+    const int aj = j0 + TP <= W ? j0 : W - TP;          // shift left at the right edge: stay in the row
+    const int ashift = j0 - aj;                         // 0..3 pixels to rotate back
     const float* ap = fm0 + (size_t)b * C * HW + ai * W + aj;
+    auto a_fetch = [&](int chunk) -> f32x4 {
+        int c = chunk * ACH + sch;
+        c = c < C ? c : C - 1;                          // clamped, zeroed below
+        return *reinterpret_cast<const f32x4u*>(ap + (size_t)c * HW);
+    };
+    auto a_put = [&](float* buf, f32x4 v, int chunk) {
+        if (tid < 4 * ACH) {
+            const bool live = chunk * ACH + sch < C;    // channels past C feed exact zeros
+            f32x4 w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {               // pixel j0+k lives at v[k + ashift] (clamped dup beyond W)
+                const int src = k + ashift < 4 ? k + ashift : 3;
+                w[k] = live ? v[src] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(buf + sch * 16 + srow * 4) = w;
+        }
+    };
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     const bool active = wave < ntg;
+    const int nchunks = (C + ACH - 1) / ACH;
 
-#define D2T_STEP(Q, KS)                                                                   \
-    {                                                                                     \
-        const float a_ = smem[((KS) * 4 + g) * 16 + n];                                   \
-        acc0 = D2T_MFMA(a_, (Q).x, acc0);                                                 \
-        acc1 = D2T_MFMA(a_, (Q).y, acc1);                                                 \
-        acc2 = D2T_MFMA(a_, (Q).z, acc2);                                                 \
-        acc3 = D2T_MFMA(a_, (Q).w, acc3);                                                 \
-    }
-
-    for (int c0 = 0; c0 < C; c0 += CA) {
-        const int cc = C - c0 < CA ? C - c0 : CA;      // channels in this pass
-        __syncthreads();
-        for (int e = tid; e < CA * 16; e += FWD_THREADS) {
-            const int c = e >> 4;                      // (e & 15) == am because FWD_THREADS % 16 == 0
-            smem[e] = c < cc ? ap[(size_t)(c0 + c) * HW] : 0.f;
-        }
-        __syncthreads();
+    a_put(smem, a_fetch(0), 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        float* cur = smem + (ch & 1) * ACH * 16;
+        const f32x4 anext = a_fetch(ch + 1 < nchunks ? ch + 1 : ch);     // lands during this chunk's MFMAs
         if (active) {
-            // Streamed operand: one 16-byte load per lane per k-step, kept PF = 4 k-steps ahead of
-            // the MFMAs that consume it.  Every load is unconditional (indices past the end are
-            // clamped to the last full k-step and simply re-read it) so that the compiler can
-            // retire them with counted s_waitcnt vmcnt(3) instead of draining the queue.
-            const float* bq = fm1 + ((size_t)b * C + c0) * HW;          // wave-uniform base
-            const int nfull = cc >> 2;
-#define D2T_LD(KS) (*reinterpret_cast<const f32x4u*>(bq + ((KS) < last ? (KS) : last) * kstride + boff))
-            if (nfull > 0) {
-                const int last = nfull - 1;
-                f32x4 q0 = D2T_LD(0), q1 = D2T_LD(1), q2 = D2T_LD(2), q3 = D2T_LD(3);
-                int ks = 0;
-                for (; ks + 3 < nfull; ks += 4) {
-                    D2T_STEP(q0, ks);     q0 = D2T_LD(ks + 4);
-                    D2T_STEP(q1, ks + 1); q1 = D2T_LD(ks + 5);
-                    D2T_STEP(q2, ks + 2); q2 = D2T_LD(ks + 6);
-                    D2T_STEP(q3, ks + 3); q3 = D2T_LD(ks + 7);
-                }
-                if (ks < nfull)     D2T_STEP(q0, ks);
-                if (ks + 1 < nfull) D2T_STEP(q1, ks + 1);
-                if (ks + 2 < nfull) D2T_STEP(q2, ks + 2);
-            }
-#undef D2T_LD
-            if (cc & 3) {                              // channel tail: lanes past C feed exact zeros
-                f32x4 qt = {0.f, 0.f, 0.f, 0.f};
-                if (nfull * 4 + g < cc) qt = *reinterpret_cast<const f32x4u*>(bq + nfull * kstride + boff);
-                D2T_STEP(qt, nfull);
+            // Straight-line body: every load is unconditional.  A lane whose channel does not
+            // exist (channel tail of the last k-step, k-steps past the end of a short last chunk)
+            // re-reads an existing channel and the value is replaced by an exact 0; its A operand
+            // is a staged 0 as well, so the accumulator is unchanged bit for bit.
+            const int k0 = ch * (ACH / 4);
+#pragma unroll 4
+            for (int kk = 0; kk < ACH / 4; ++kk) {
+                const int c = 4 * (k0 + kk) + g;                 // this lane's channel
+                const bool live = c < C;
+                const int cl = live ? c : C - 1;
+                f32x4 q = *reinterpret_cast<const f32x4u*>(bp + (size_t)(cl - g) * HW);
+                q = live ? q : f32x4{0.f, 0.f, 0.f, 0.f};
+                const float a_ = cur[(kk * 4 + g) * 16 + n];
+                acc0 = D2T_MFMA(a_, q.x, acc0);
+                acc1 = D2T_MFMA(a_, q.y, acc1);
+                acc2 = D2T_MFMA(a_, q.z, acc2);
+                acc3 = D2T_MFMA(a_, q.w, acc3);
             }
         }
+        a_put(smem + ((ch + 1) & 1) * ACH * 16, anext, ch + 1);
+        __syncthreads();
     }
-#undef D2T_STEP
 
     // ---- epilogue: out tile [16 pixels][17][17] through LDS ----
     __syncthreads();
@@ -220,7 +221,6 @@ constexpr int ST_THREADS = ST_WAVES * 64;
 constexpr int ST_CH = ST_WAVES * 16;                // channels per workgroup pass
 constexpr int NACT = 5;                             // tiles alive during one super-step
 constexpr int KB_SS = 5;                            // k-blocks per super-step
-constexpr int RING = NACT * 256;                    // floats of G per k-block: [tile][lane][4]
 // (1600 of the 2048 quad slots of a super-step are real: 5 k-blocks x 5 tiles x 64 lanes)
 constexpr int Q_PER_THREAD = 2;                     // every thread produces 2 quads: 2048 slots, 448 unused
 constexpr int RING_SS = Q_PER_THREAD * ST_THREADS * 4;   // 8192 floats = 32 KB per buffer
