@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""bench_ops.py -- secondary benchmark: every op of the hot path at the shapes BASELINE.json and
+SURVEY.md section 8d name, one JSON line per (op, shape, direction).  Not the driver's contract
+(that is bench.py); used for DESIGN.md's tables and the rocprof summaries under profiles/.
+
+    python bench_ops.py [--iters 50] [--impl 0|1]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
+from detect_to_track.models import _ext  # noqa: E402
+
+HBM = 8000.0
+
+
+def random_rois(R, seed):
+    rng = np.random.default_rng(seed)
+    return np.concatenate([rng.uniform(0.15, 0.85, (R, 2)), rng.uniform(0.05, 0.6, (R, 2))], 1).astype(np.float32)
+
+
+def timed(fn, iters, nsets):
+    for i in range(3):
+        fn(i % nsets)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(iters):
+        fn(i % nsets)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3           # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--impl", type=int, default=0)
+    args = ap.parse_args()
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    out = []
+
+    def emit(op, shape, direction, us, nbytes, extra=None):
+        line = dict(op=op, shape=shape, dir=direction, us=round(us, 2), algo_MB=round(nbytes / 1e6, 3),
+                    GBps=round(nbytes / us / 1e3, 1), pct_hbm=round(100 * nbytes / us / 1e3 / HBM, 2), impl=args.impl)
+        if extra:
+            line.update(extra)
+        print(json.dumps(line), flush=True)
+
+    # ---- pooling, config 3 and the model-true shapes
+    k = 7
+    for name, C, H, W, R in (("roipool", 1024, 38, 63, 300), ("roipool", 1891, 38, 75, 8)):
+        nsets = max(2, int(600e6 // (R * C * k * k * 8 + C * H * W * 8)) + 1)
+        nsets = min(nsets, 8)
+        fm = [torch.rand(C, H, W, device=dev) for _ in range(nsets)]
+        go = [torch.rand(R, C, k, k, device=dev) for _ in range(nsets)]
+        rois = torch.from_numpy(random_rois(R, 0)).to(dev)
+        nb = R * C * k * k * 4 + C * H * W * 4 + R * 16
+        emit(name, f"R{R}_C{C}_{H}x{W}_k{k}", "fwd", timed(lambda i: _ext.roipool_forward(fm[i], rois, k, args.impl), args.iters, nsets), nb)
+        emit(name, f"R{R}_C{C}_{H}x{W}_k{k}", "bwd", timed(lambda i: _ext.roipool_backward(go[i], rois, H, W, args.impl), args.iters, nsets), nb)
+        del fm, go
+    for nT, H, W, R in ((21, 38, 63, 300), (31, 38, 75, 300), (4, 38, 75, 300), (31, 38, 75, 3000), (4, 38, 75, 3000)):
+        C = nT * k * k
+        fm = [torch.rand(C, H, W, device=dev) for _ in range(4)]
+        go = [torch.rand(R, nT, k, k, device=dev) for _ in range(4)]
+        rois = torch.from_numpy(random_rois(R, 1)).to(dev)
+        nb = R * nT * k * k * 4 + C * H * W * 4 + R * 16
+        emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "fwd", timed(lambda i: _ext.ps_roipool_forward(fm[i], rois, nT, k, args.impl), args.iters, 4), nb)
+        emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "bwd", timed(lambda i: _ext.ps_roipool_backward(go[i], rois, H, W, args.impl), args.iters, 4), nb)
+
+    # ---- correlation: metric shape, config 2, model-true shapes
+    for B, C, H, W in ((8, 256, 38, 63), (1, 256, 38, 63), (1, 512, 38, 75), (1, 1024, 38, 75), (1, 2048, 38, 75)):
+        d = 8
+        nsets = 6 if B > 1 else 8
+        f0 = [torch.rand(B, C, H, W, device=dev) for _ in range(nsets)]
+        f1 = [torch.rand(B, C, H, W, device=dev) for _ in range(nsets)]
+        go = [torch.rand(B, H, W, 17, 17, device=dev) for _ in range(nsets)]
+        inb, outb = B * C * H * W * 4, B * H * W * 289 * 4
+        vox = B * H * W * 289
+        tf = timed(lambda i: _ext.pointwise_correlation_forward(f0[i], f1[i], d, 1, args.impl), args.iters, nsets)
+        tb = timed(lambda i: _ext.pointwise_correlation_backward(go[i], f0[i], f1[i], d, 1, args.impl), args.iters, nsets)
+        emit("corr", f"B{B}_C{C}_{H}x{W}_d8", "fwd", tf, 2 * inb + outb, dict(gvox_s=round(vox / tf / 1e3, 2)))
+        emit("corr", f"B{B}_C{C}_{H}x{W}_d8", "bwd", tb, outb + 4 * inb, dict(gvox_s=round(vox / tb / 1e3, 2)))
+        del f0, f1, go
+
+
+if __name__ == "__main__":
+    main()

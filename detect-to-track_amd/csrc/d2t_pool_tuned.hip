@@ -1,13 +1,400 @@
-// placeholder -- filled in by the tuned pooling kernels
+// d2t_pool_tuned.hip -- gfx950-tuned f32 ROIPool / PSROIPool kernels (k = 7).
+//
+// The pooling ops are byte movers (ROIPool config 3: 60 MB of output against 10 MB of input and
+// ~0 flops), so the design goal is coalescing, not arithmetic:
+//
+//  * ROIPool works CHANNEL-LAST.  A pre-pass transposes the (C,H,W) map to (H*W, C) in the
+//    workspace; then one wave owns (RoI, 64 consecutive channels) with one channel per lane.
+//    Every bin bound is wave-uniform (scalar registers, scalar loads from the bin table), every
+//    feature load is a full 256-byte row of 64 channels of one pixel, and each lane keeps the
+//    reference's running sum over its bin in the reference's own pixel order (roipool_cuda.cu:56-61)
+//    -- forward results stay BIT-IDENTICAL to the reference.  The 64 x 49 results of a wave are
+//    exactly one contiguous 12.5 KB run of the (R,C,7,7) output; they are transposed through LDS
+//    and stored as full 256-byte rows.
+//  * ROIPool backward (gather form): gradOut is transposed once to (R, 49, C); a workgroup owns
+//    (64 channels, one map row), each of its waves walks a share of the RoIs (wave-uniform
+//    geometry) and adds gradOut/n into an LDS accumulator [W][65] that it alone touches (plain
+//    read-add-write, one channel per lane); the partial rows are added in a fixed order.
+//  * PSROIPool backward, phase 1: a workgroup owns one OUTPUT plane (t, bin) -- every plane has
+//    exactly R cells, so the grid is balanced whatever the many-to-one channel map
+//    ((t+1)*bin, ps_roipool_cuda.cu:58) does.  Its 4 waves own bands of map rows, a lane owns the
+//    pixels of its column(s) in the band, accumulators live in REGISTERS.  64 RoIs are fetched
+//    and tested per instruction (lane = RoI, ballot), the hits are then visited in ascending
+//    order out of registers (v_readlane).  Phase 2 adds, per input channel, the planes that map
+//    to it in ascending (bin, t) order.
+//  No atomics of any kind (global or LDS), no accumulator shared between waves, every gradIn
+//  element written once, fixed summation order: bitwise reproducible.
+#include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
+
 namespace d2t { namespace tuned {
-bool   roipool_fwd_supported(int, int, int, int, int) { return false; }
-size_t roipool_fwd_ws_bytes(int, int, int, int, int) { return 0; }
-int    roipool_fwd_f32(const float*, const float*, float*, int, int, int, int, int, void*, hipStream_t) { return D2T_EINVAL; }
-bool   roipool_bwd_supported(int, int, int, int, int) { return false; }
-size_t roipool_bwd_ws_bytes(int, int, int, int, int) { return 0; }
-int    roipool_bwd_f32(const float*, const float*, float*, int, int, int, int, int, void*, hipStream_t) { return D2T_EINVAL; }
-bool   psroipool_bwd_supported(int, int, int, int, int) { return false; }
-size_t psroipool_bwd_ws_bytes(int, int, int, int, int) { return 0; }
-int    psroipool_bwd_f32(const float*, const float*, float*, int, int, int, int, int, void*, hipStream_t) { return D2T_EINVAL; }
-}}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KT = 7;                         // r_hw the tuned pooling kernels are built for
+constexpr int KK = KT * KT;
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+inline size_t bins_bytes(int R) { return align256((size_t)R * KK * 4 * sizeof(int32_t)); }
+
+// ---------------------------------------------------------------------------------------
+// (rows, cols) -> (cols, rows) transpose of a row-major f32 matrix, 32x32 tiles through LDS.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows, int cols)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * k][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+static int transpose(const float* in, float* out, int rows, int cols, hipStream_t st)
+{
+    if (rows == 0 || cols == 0) return D2T_OK;
+    hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows, cols);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-RoI geometry record: 32 int32 = {i0[7], i1[7], j0[7], j1[7], top, bottom, left, right}.
+// Row bounds of a bin depend on i only, column bounds on j only (roipool_cuda.cu:41-50), so 28
+// numbers describe all 49 bins; one record is two s_load_dwordx16 for a wave.
+// ---------------------------------------------------------------------------------------
+constexpr int GEO = 32;
+inline size_t geo_bytes(int R) { return align256((size_t)R * GEO * sizeof(int32_t)); }
+
+__global__ void __launch_bounds__(64)
+k_roi_geom(const float* __restrict__ rois, int32_t* __restrict__ geo, int R, int H, int W)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    int32_t* g = geo + (size_t)r * GEO;
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+        const Bounds b = roi_bin<float>(rois + 4 * r, i, i, H, W, KT);     // (i, i): row bounds of i, column bounds of j = i
+        g[i] = b.i0; g[KT + i] = b.i1; g[2 * KT + i] = b.j0; g[3 * KT + i] = b.j1;
+    }
+    g[28] = g[0]; g[29] = g[2 * KT - 1]; g[30] = g[2 * KT]; g[31] = g[4 * KT - 1];
+}
+
+static int roi_geom(const float* rois, int32_t* geo, int R, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_roi_geom, dim3((R + 63) / 64), dim3(64), 0, st, rois, geo, R, H, W);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// ROIPool forward, channel-last.  fmt: (H*W, C).  Workgroup = (RoI, 64 channels) = 7 waves, wave
+// i owns bin row i: 7 accumulators (one per bin column) per lane, one channel per lane.  The
+// column loops of the 7 bins advance together (step k = k-th pixel of every bin), so 7 independent
+// 256-byte loads are in flight per step while each accumulator still sees its bin's pixels in the
+// reference's row-major order.  The 64 x 49 block is assembled in LDS and stored as one
+// contiguous 12.5 KB run.
+// ---------------------------------------------------------------------------------------
+constexpr int RF_THREADS = KT * 64;
+
+__global__ void __launch_bounds__(RF_THREADS)
+k_roipool_fwd_cl(const float* __restrict__ fmt, const int32_t* __restrict__ geo, float* __restrict__ out,
+                 int C, int W)
+{
+    __shared__ float stage[64 * KK + 16];                            // 12.6 KB
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index = bin row (wave-uniform)
+    const int r = blockIdx.x, c0 = blockIdx.y * 64;
+    const int c = c0 + lane < C ? c0 + lane : C - 1;                 // clamped lane channel; masked at the store
+    const int32_t* g = geo + (size_t)r * GEO;
+    const int i0 = __builtin_amdgcn_readfirstlane(g[i]), i1 = __builtin_amdgcn_readfirstlane(g[KT + i]);
+    int j0[KT], wj[KT], wmax = 0;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        j0[j] = __builtin_amdgcn_readfirstlane(g[2 * KT + j]);
+        wj[j] = __builtin_amdgcn_readfirstlane(g[3 * KT + j]) - j0[j];
+        wmax = wj[j] > wmax ? wj[j] : wmax;
+    }
+    float acc[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) acc[j] = 0.f;
+    const float* base = fmt + c;
+    for (int pI = i0; pI < i1; ++pI) {
+        const float* row = base + (size_t)pI * W * C;
+        for (int k = 0; k < wmax; ++k) {
+            float v[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {                           // 7 independent loads; a bin that is
+                int col = j0[j] + (k < wj[j] ? k : 0);               // already exhausted re-reads its first
+                col = wj[j] > 0 ? col : 0;                           // pixel (or pixel 0) and adds an exact 0
+                v[j] = row[(size_t)col * C];
+            }
+#pragma unroll
+            for (int j = 0; j < KT; ++j) acc[j] += k < wj[j] ? v[j] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const int n = (i1 - i0) * wj[j];
+        stage[lane * KK + i * KT + j] = acc[j] / static_cast<float>(n);     // 0/0 = NaN as the reference
+    }
+    __syncthreads();
+    const int nch = C - c0 < 64 ? C - c0 : 64;
+    float* dst = out + ((size_t)r * C + c0) * KK;
+    for (int e = threadIdx.x; e < nch * KK; e += RF_THREADS) dst[e] = stage[e];
+}
+
+bool roipool_fwd_supported(int R, int C, int H, int W, int k)
+{
+    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && (C + 63) / 64 <= 65535;
+}
+
+size_t roipool_fwd_ws_bytes(int R, int C, int H, int W, int k)
+{
+    if (!roipool_fwd_supported(R, C, H, W, k)) return 0;
+    return align256((size_t)C * H * W * sizeof(float)) + geo_bytes(R);
+}
+
+int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int,
+                    void* ws, hipStream_t st)
+{
+    float* fmt = static_cast<float*>(ws);
+    int32_t* geo = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + align256((size_t)C * H * W * sizeof(float)));
+    int rc = transpose(fm, fmt, C, H * W, st);                       // (C, HW) -> (HW, C)
+    if (rc != D2T_OK) return rc;
+    rc = roi_geom(rois, geo, R, H, W, st);
+    if (rc != D2T_OK) return rc;
+    hipLaunchKernelGGL(k_roipool_fwd_cl, dim3(R, (C + 63) / 64), dim3(RF_THREADS), 0, st, fmt, geo, out, C, W);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// ROIPool backward, channel-last gather.  gt: gradOut transposed to (R, 49, C).
+// Workgroup = (map row y, 64 channels); wave w walks RoIs [w*R/NW, (w+1)*R/NW) and adds
+// gradOut/n into its own LDS accumulator [W][65] (lane = channel); the partial rows are added in
+// a fixed order and stored as 64 rows of gradIn.
+// ---------------------------------------------------------------------------------------
+constexpr int RB_LD = 65;
+
+template <int RB_WAVES>                                              // 4 waves for W <= 63, 2 for W <= 126 (64 KB of LDS)
+__global__ void __launch_bounds__(RB_WAVES * 64)
+k_roipool_bwd_cl(const float* __restrict__ gt, const int32_t* __restrict__ geo, float* __restrict__ gin,
+                 int R, int C, int H, int W)
+{
+    extern __shared__ float accs[];                                  // [RB_WAVES][W][65]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int y = blockIdx.x, c0 = blockIdx.y * 64;
+    const int c = c0 + lane < C ? c0 + lane : C - 1;
+    float* acc = accs + (size_t)wave * W * RB_LD;
+    for (int x = 0; x < W; ++x) acc[x * RB_LD + lane] = 0.f;
+
+    const int r_lo = (int)((long long)R * wave / RB_WAVES), r_hi = (int)((long long)R * (wave + 1) / RB_WAVES);
+    for (int r = r_lo; r < r_hi; ++r) {
+        const int32_t* g = geo + (size_t)r * GEO;                    // wave-uniform: scalar loads
+        if (y < g[28] || y >= g[29]) continue;                       // row outside the RoI
+        const float* gr = gt + (size_t)r * KK * C + c;
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            const int i0 = g[i], i1 = g[KT + i];
+            if (y < i0 || y >= i1) continue;                         // uniform
+            float v[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) v[j] = gr[(size_t)(i * KT + j) * C];   // 7 coalesced loads in flight
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const int j0 = g[2 * KT + j], j1 = g[3 * KT + j];
+                if (j1 <= j0) continue;
+                const float q = v[j] / static_cast<float>((i1 - i0) * (j1 - j0));     // roipool_cuda.cu:123
+                for (int x = j0; x < j1; ++x) acc[x * RB_LD + lane] += q;             // ascending (r,i,j)
+            }
+        }
+    }
+    __syncthreads();
+    // gin[c0+ch][y][0..W): lanes along x, fixed-order sum of the partial rows
+    const int nch = C - c0 < 64 ? C - c0 : 64;
+    const int per = W * RB_LD;
+    for (int e = threadIdx.x; e < nch * W; e += RB_WAVES * 64) {
+        const int ch = e / W, x = e - ch * W;
+        const int o = x * RB_LD + ch;
+        float a = accs[o];
+#pragma unroll
+        for (int w = 1; w < RB_WAVES; ++w) a += accs[w * per + o];   // fixed order
+        gin[((size_t)(c0 + ch) * H + y) * W + x] = a;
+    }
+}
+
+// batched (C x 49) -> (49 x C) transpose: block = one RoI x 64 channels
+__global__ void __launch_bounds__(256)
+k_transpose_gout(const float* __restrict__ in, float* __restrict__ out, int C)
+{
+    __shared__ float t[64 * KK + 8];
+    const int r = blockIdx.x, c0 = blockIdx.y * 64;
+    const int nch = C - c0 < 64 ? C - c0 : 64;
+    const float* src = in + ((size_t)r * C + c0) * KK;
+    for (int e = threadIdx.x; e < nch * KK; e += 256) t[e] = src[e];
+    __syncthreads();
+    float* dst = out + (size_t)r * KK * C + c0;
+    for (int e = threadIdx.x; e < KK * 64; e += 256) {
+        const int b = e >> 6, ch = e & 63;
+        if (ch < nch) dst[(size_t)b * C + ch] = t[ch * KK + b];
+    }
+}
+
+bool roipool_bwd_supported(int R, int C, int H, int W, int k)
+{
+    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && (C + 63) / 64 <= 65535 &&
+           (size_t)2 * W * RB_LD * sizeof(float) <= 64 * 1024;
+}
+
+size_t roipool_bwd_ws_bytes(int R, int C, int H, int W, int k)
+{
+    if (!roipool_bwd_supported(R, C, H, W, k)) return 0;
+    return align256((size_t)R * C * KK * sizeof(float)) + geo_bytes(R);
+}
+
+int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int,
+                    void* ws, hipStream_t st)
+{
+    float* gt = static_cast<float*>(ws);
+    int32_t* geo = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + align256((size_t)R * C * KK * sizeof(float)));
+    hipLaunchKernelGGL(k_transpose_gout, dim3(R, (C + 63) / 64), dim3(256), 0, st, gout, gt, C);   // (R,C,49) -> (R,49,C)
+    int rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    rc = roi_geom(rois, geo, R, H, W, st);
+    if (rc != D2T_OK) return rc;
+    const dim3 grid(H, (C + 63) / 64);
+    if ((size_t)4 * W * RB_LD * sizeof(float) <= 64 * 1024)
+        hipLaunchKernelGGL(k_roipool_bwd_cl<4>, grid, dim3(256), (size_t)4 * W * RB_LD * sizeof(float), st,
+                           gt, geo, gin, R, C, H, W);
+    else
+        hipLaunchKernelGGL(k_roipool_bwd_cl<2>, grid, dim3(128), (size_t)2 * W * RB_LD * sizeof(float), st,
+                           gt, geo, gin, R, C, H, W);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Pixel ownership of the PSROIPool backward: 4 waves x bands of <= PX_ROWS rows, lane = column
+// (two column groups for maps wider than 64).
+// ---------------------------------------------------------------------------------------
+constexpr int PX_MAXROWS = 16;               // rows per wave band: H <= 64
+constexpr int PX_XG = 2;                     // column groups: W <= 128
+
+// ---------------------------------------------------------------------------------------
+// PSROIPool backward, phase 1.  Workgroup = output plane (t, bin).  cells: (R,7,7,4) int32.
+// part[plane][y][x] = sum over RoIs r whose cell `bin` contains (y,x) of gout[r,t,bin] / n
+// (ps_roipool_cuda.cu:131-139), ascending r.
+// ---------------------------------------------------------------------------------------
+template <int PX_ROWS>                       // band height the row loop is unrolled for (10: H <= 40)
+__global__ void __launch_bounds__(256)
+k_psroipool_bwd_plane(const float* __restrict__ gout, const int32_t* __restrict__ cells, float* __restrict__ part,
+                      int R, int nT, int H, int W)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int plane = blockIdx.x, bin = plane % KK;                  // plane = t*49 + bin
+    const int band = (H + 3) >> 2;
+    const int y_lo = wave * band, y_hi = y_lo + band < H ? y_lo + band : H;
+    float acc[PX_ROWS][PX_XG];
+#pragma unroll
+    for (int k = 0; k < PX_ROWS; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; }
+
+    if (y_lo < y_hi) {
+        const int4* ct = reinterpret_cast<const int4*>(cells) + bin;
+        const float* gp = gout + plane;
+        for (int rb = 0; rb < R; rb += 64) {
+            // 64 RoIs per instruction: lane l fetches and tests RoI rb+l
+            const int rr = rb + lane;
+            int4 cb = make_int4(0, 0, 0, 0);
+            float v = 0.f;
+            if (rr < R) {
+                cb = ct[(size_t)rr * KK];
+                v = gp[(size_t)rr * nT * KK];
+            }
+            const int n = (cb.y - cb.x) * (cb.w - cb.z);
+            const bool hit = cb.y > cb.x && cb.w > cb.z && cb.y > y_lo && cb.x < y_hi;
+            v = v / static_cast<float>(n > 0 ? n : 1);               // ps_roipool_cuda.cu:135
+            unsigned long long m = __ballot(hit);
+            while (m) {                                              // ascending r
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int i0 = __builtin_amdgcn_readlane(cb.x, l), i1 = __builtin_amdgcn_readlane(cb.y, l);
+                const int j0 = __builtin_amdgcn_readlane(cb.z, l), j1 = __builtin_amdgcn_readlane(cb.w, l);
+                const float vv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                const float v0 = (lane >= j0 && lane < j1) ? vv : 0.f;
+                const float v1 = (lane + 64 >= j0 && lane + 64 < j1) ? vv : 0.f;
+#pragma unroll
+                for (int k = 0; k < PX_ROWS; ++k) {
+                    const int y = y_lo + k;
+                    if (y >= i0 && y < i1 && y < y_hi) { acc[k][0] += v0; acc[k][1] += v1; }   // wave-uniform
+                }
+            }
+        }
+    }
+    float* dst = part + (size_t)plane * H * W;
+#pragma unroll
+    for (int k = 0; k < PX_ROWS; ++k) {
+        const int y = y_lo + k;
+        if (y < y_hi) {
+            if (lane < W) dst[y * W + lane] = acc[k][0];
+            if (lane + 64 < W) dst[y * W + lane + 64] = acc[k][1];
+        }
+    }
+}
+
+// phase 2: gin[ch] = sum of the planes (t, bin) with (t+1)*bin == ch, ascending bin then t;
+// channels nothing maps to are zero.
+__global__ void __launch_bounds__(256)
+k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, int nT, int HW)
+{
+    const int ch = blockIdx.y;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        float a = 0.f;
+        if (ch == 0) {
+            for (int t = 0; t < nT; ++t) a += part[(size_t)(t * KK) * HW + p];
+        } else {
+            for (int bin = 1; bin < KK; ++bin) {
+                if (ch % bin != 0) continue;
+                const int tp1 = ch / bin;
+                if (tp1 <= nT) a += part[(size_t)((tp1 - 1) * KK + bin) * HW + p];
+            }
+        }
+        gin[(size_t)ch * HW + p] = a;
+    }
+}
+
+bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
+{
+    return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && H <= 4 * PX_MAXROWS && W <= 64 * PX_XG && nT * KK <= 65535;
+}
+
+size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
+{
+    if (!psroipool_bwd_supported(R, nT, H, W, k)) return 0;
+    return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float));
+}
+
+int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
+                      void* ws, hipStream_t st)
+{
+    int32_t* cells = static_cast<int32_t*>(ws);
+    float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + bins_bytes(R));
+    int rc = psroipool_bins<float>(rois, cells, R, H, W, k, st);
+    if (rc != D2T_OK) return rc;
+    if (H <= 40)
+        hipLaunchKernelGGL(k_psroipool_bwd_plane<10>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
+    else
+        hipLaunchKernelGGL(k_psroipool_bwd_plane<PX_MAXROWS>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
+    rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    const int HW = H * W;
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
+    return launch_status();
+}
+
+}}  // namespace d2t::tuned
