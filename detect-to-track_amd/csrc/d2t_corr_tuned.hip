@@ -430,33 +430,54 @@ constexpr int KB_SS = 5;                            // k-blocks per super-step
 constexpr int Q_PER_THREAD = 2;                     // every thread produces 2 quads: 2048 slots, 448 unused
 constexpr int RING_SS = Q_PER_THREAD * ST_THREADS * 4;   // 8192 floats = 32 KB per buffer
 
-// Four consecutive elements (columns s = 0..3) of the G ring for k-block 5*ss + q, live tile a,
-// lane l.  The cell inside a gradOut row depends only on (q, a, l); the row advances by 4 map
-// rows per super-step.  role 0: the four cells are adjacent in one gradOut row; role 1: they sit
-// in four adjacent centre pixels, one cell to the left each time.
-__device__ __forceinline__ f32x4 strip_quad(const float* __restrict__ gb, int role, int ss, int q, int a, int l,
-                                            int H, int W, int tiles_i, int j0, int col0)
+// Descriptor of one G-ring quad (k-block q of a super-step, live tile a, lane l): four
+// consecutive columns s = 0..3 of one (tile pixel, slot group) pair.  Everything that does not
+// depend on the super-step is folded into it once per workgroup:
+//   the quad reads gradOut[off0 + ss*step + dp*s] for the s whose bit is set in `mask`, provided
+//   lo <= ss < hi (tile row exists, tile pixel and slot row inside the map); otherwise exact 0.
+// role 0: the four cells are adjacent in one gradOut row (dp = 1); role 1: they sit in four
+// adjacent centre pixels, one cell to the left each time (dp = 289 - 1).
+struct QuadDesc { int off0, lo, hi, mask; };
+
+__device__ __forceinline__ QuadDesc strip_quad_desc(int role, int e, int H, int W, int tiles_i, int j0, int col0)
 {
-    const int t = l & 15, gg = l >> 4;
-    const int u = ss - 2 + a;                                       // tile row
-    const int x = 4 * q + gg, xr = (x * 13) >> 6, cg = x - xr * NCG; // x / 5, x % 5 for x in 0..19
-    const int rho = 4 * ss + xr;                                    // slot row
-    const int ti = 4 * u + (t >> 2), tj = j0 + (t & 3);             // tile pixel
-    const int sj = col0 + 4 * cg;                                   // first slot column (all 4 in the map)
-    const int ci = role ? ti - rho + DT : rho - ti + DT;            // displaced - centre + d
-    const int cj = role ? tj - sj + DT : sj - tj + DT;              // for s = 0; role 0: +s, role 1: -s
-    const bool ok = u >= 0 && u < tiles_i && ti < H && tj < W && rho < H && ci >= 0 && ci < 2 * DT;
-    const int pix = role ? rho * W + sj : ti * W + tj;              // centre pixel for s = 0
-    const int off = pix * CELLS + ci * CW + cj;                     // fits int32 (checked by the C ABI)
-    const int dp = role ? CELLS - 1 : 1;                            // next s: next centre & cell-1, or cell+1
+    const int q = e / (NACT * 64), r = e - q * (NACT * 64);
+    const int a = r >> 6, l = r & 63, t = l & 15, gg = l >> 4;
+    const int x = 4 * q + gg, xr = (x * 13) >> 6, cg = x - xr * NCG;      // x / 5, x % 5 (x < 32)
+    const int tpi = t >> 2, tj = j0 + (t & 3), sj = col0 + 4 * cg;
+    // at super-step ss: tile row u = ss-2+a, tile pixel row ti = 4u+tpi, slot row rho = 4ss+xr
+    const int ci = role ? 4 * a + tpi - xr : xr - 4 * a - tpi + 2 * DT;    // displaced - centre + d (constant)
+    const int cj = role ? tj - sj + DT : sj - tj + DT;                     // for s = 0; role 0: +s, role 1: -s
     const int dc = role ? -1 : 1;
-    f32x4 v;
-    // branch-free: an element that is not needed loads gb[0] and is replaced by 0
+    QuadDesc d;
+    d.mask = 0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int c = cj + dc * s;
-        const bool use = ok && c >= 0 && c < 2 * DT;
-        const float x_ = gb[use ? off + dp * s : 0];
+    for (int s = 0; s < 4; ++s) d.mask |= (cj + dc * s >= 0 && cj + dc * s < 2 * DT) ? (1 << s) : 0;
+    if (ci < 0 || ci >= 2 * DT || tj >= W || q >= KB_SS) d.mask = 0;
+    // centre pixel at ss = 0 (may be negative: only dereferenced when lo <= ss)
+    const int pix0 = role ? xr * W + sj : (4 * (a - 2) + tpi) * W + tj;
+    d.off0 = pix0 * CELLS + ci * CW + cj;
+    // validity window in ss: 0 <= u < tiles_i, ti < H, rho < H
+    int lo = 2 - a, hi = tiles_i + 2 - a;
+    const int hi_t = (H - tpi + 3) / 4 + 2 - a;                            // 4(ss-2+a)+tpi < H
+    const int hi_r = (H - xr + 3) / 4;                                     // 4ss+xr < H
+    hi = hi < hi_t ? hi : hi_t;
+    hi = hi < hi_r ? hi : hi_r;
+    d.lo = lo < 0 ? 0 : lo;
+    d.hi = hi;
+    return d;
+}
+
+__device__ __forceinline__ f32x4 strip_quad_load(const float* __restrict__ gb, const QuadDesc& d, int ss,
+                                                 int step, int dp)
+{
+    const bool in = ss >= d.lo && ss < d.hi;
+    const int base = d.off0 + ss * step;
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                                          // branch-free: unused -> gb[0] -> 0
+        const bool use = in && ((d.mask >> s) & 1);
+        const float x_ = gb[use ? base + dp * s : 0];
         v[s] = use ? x_ : 0.f;
     }
     return v;
@@ -503,18 +524,17 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
             if (c < C) gx[((size_t)b * C + c) * HW + i * W + j] = d[r];
         }
     };
-    // quad k of this thread in a super-step's ring: slot tid + k*1024 = (q, a, lane); slots >= 1600
-    // are padding (they decode to q >= 5, rows that belong to the next super-step: never read)
-    auto g_quad = [&](int ss, int k) -> f32x4 {
-        const int e = tid + k * ST_THREADS;
-        const int q = e / (NACT * 64), r = e - q * (NACT * 64);
-        return strip_quad(gb, role, ss, q, r >> 6, r & 63, H, W, tiles_i, j0, col0);
-    };
+    // the two ring quads this thread produces every super-step (slots >= 1600 are padding: mask 0)
+    const QuadDesc qd0 = strip_quad_desc(role, tid, H, W, tiles_i, j0, col0);
+    const QuadDesc qd1 = strip_quad_desc(role, tid + ST_THREADS, H, W, tiles_i, j0, col0);
+    const int gstep = 4 * W * CELLS;                                  // gradOut offset of 4 map rows
+    const int gdp = role ? CELLS - 1 : 1;
 
-    // prologue: ring[0] <- super-step 0
-#pragma unroll
-    for (int k = 0; k < Q_PER_THREAD; ++k)
-        reinterpret_cast<f32x4*>(ring[0])[tid + k * ST_THREADS] = g_quad(0, k);
+    // prologue: ring[0] <- super-step 0, registers <- super-step 1
+    reinterpret_cast<f32x4*>(ring[0])[tid] = strip_quad_load(gb, qd0, 0, gstep, gdp);
+    reinterpret_cast<f32x4*>(ring[0])[tid + ST_THREADS] = strip_quad_load(gb, qd1, 0, gstep, gdp);
+    f32x4 gn0 = strip_quad_load(gb, qd0, 1, gstep, gdp);
+    f32x4 gn1 = strip_quad_load(gb, qd1, 1, gstep, gdp);
     f32x4 av = s_load(0, 0);
     __syncthreads();
 
@@ -523,9 +543,6 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
     for (int ss = 0; ss < tiles_i; ++ss) {
         const int cur = ss & 1;
         const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
-        f32x4 gn[Q_PER_THREAD];
-#pragma unroll
-        for (int k = 0; k < Q_PER_THREAD; ++k) gn[k] = g_quad(ss + 1, k);   // past the map: all zeros
 #pragma unroll
         for (int q = 0; q < KB_SS; ++q) {
             const f32x4 a4 = av;
@@ -539,9 +556,13 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
                 for (int a = 0; a < NACT; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
             }
         }
-#pragma unroll
-        for (int k = 0; k < Q_PER_THREAD; ++k)
-            reinterpret_cast<f32x4*>(ring[cur ^ 1])[tid + k * ST_THREADS] = gn[k];
+        // hand super-step ss+1's G (requested a whole super-step ago) to the other buffer, then
+        // request ss+2's: these loads are the YOUNGEST in the queue, so no FM load of the next
+        // super-step has to wait behind them (vmcnt retires in order)
+        reinterpret_cast<f32x4*>(ring[cur ^ 1])[tid] = gn0;
+        reinterpret_cast<f32x4*>(ring[cur ^ 1])[tid + ST_THREADS] = gn1;
+        gn0 = strip_quad_load(gb, qd0, ss + 2, gstep, gdp);          // past the map: all zeros
+        gn1 = strip_quad_load(gb, qd1, ss + 2, gstep, gdp);
         __syncthreads();
         store_tile(acc[0], ss - 2);                                  // complete after its 5th super-step
 #pragma unroll
