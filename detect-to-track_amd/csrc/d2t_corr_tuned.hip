@@ -367,6 +367,228 @@ k_corr_fwd_strip(const float* __restrict__ fm0, const float* __restrict__ fm1, f
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Forward, LDS-staged segment kernel (the default when the grid fills the chip).
+// The tile kernel above gathers every p-tile's 19 x 20 window straight from L2 in 80-byte row
+// pieces; rocprofv3 shows its texture-address unit 85 % busy (TA_TA_BUSY) at ~25 useful bytes per
+// 64-byte sector, i.e. it is bound by the gather, not by MFMA or HBM.  Here one workgroup owns a
+// segment of 5 vertically stacked p-tiles: the union of their windows (<= 35 rows x 20 columns) is
+// copied ONCE per 16 channels into LDS (2.7x fewer bytes through the TA), and every wave reads its
+// MFMA fragments from there with conflict-free ds_read_b128 (a tile's window rows are contiguous
+// in the image, so a tile-group is 16 consecutive 16-byte slots).  A wave owns two (tile,
+// tile-group) tasks.  At B=8, 38x63 the grid is 8 x 16 x 2 = 256 workgroups of exactly 5 tiles:
+// one per CU.  Arithmetic is unchanged (ascending-channel MFMA chain): bit-identical results.
+// ------------------------------------------------------------------------------------
+constexpr int SG_NU = 5;                            // p-tiles per segment
+constexpr int SG_NU1 = 5;                           // tiles of the first pass (5 = single pass)
+constexpr int SG_WAVES = 15;                        // 30 (tile, tile-group) tasks, two per wave
+constexpr int SG_THREADS = SG_WAVES * 64;
+constexpr int SG_KC = 16;                           // channels per staged chunk (4 k-steps)
+constexpr int SG_ROWS = 4 * SG_NU + 2 * DT - 1;     // 35 window rows of a segment
+constexpr int SG_BPL = SG_ROWS * WC;                // 700 floats: FM1 region of one channel
+constexpr int SG_APL = SG_NU * 16;                  // 80 floats: FM0 pixels of one channel
+constexpr int SG_BUF = SG_KC * (SG_BPL + SG_APL);   // floats per buffer (48.75 KB)
+constexpr int SG_STAGE = SG_NU * 16 * CELLS;        // out staging (90.3 KB), aliases the buffers
+constexpr int SG_LDS = 2 * SG_BUF > SG_STAGE ? 2 * SG_BUF : SG_STAGE;
+
+constexpr int SG_NPB = SG_KC * SG_ROWS * NCG;       // 2800 FM1 pieces (16 bytes) per chunk
+constexpr int SG_NPA = SG_KC * 4 * SG_NU;           // 320 FM0 pieces per chunk
+constexpr int SG_BI = (SG_NPB + 63) / 64;           // 44 wave-instructions move the FM1 region of a chunk
+constexpr int SG_BIW = (SG_BI + SG_WAVES - 1) / SG_WAVES;   // 3 per wave
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__global__ void __launch_bounds__(SG_THREADS)
+k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
+               int C, int H, int W, int tiles_i, int tiles_j, int nseg)
+{
+    __shared__ __attribute__((aligned(16))) float smem[SG_LDS];
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
+    const int useg0 = seg * SG_NU, nuseg = tiles_i - useg0 < SG_NU ? tiles_i - useg0 : SG_NU;
+    const int j0 = tj * TP, HW = H * W;
+    const unsigned plane_bytes = (unsigned)C * HW * 4u;
+    const __amdgpu_buffer_rsrc_t r1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm1 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm0 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * HW * CELLS, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
+
+  // The segment is processed in two passes (3 tiles, then the rest): the first pass's outputs are
+  // stored WRITE-THROUGH (sc1) and drain to HBM while the second pass computes, so that only the
+  // second pass's stores (40 % of the segment) are left for the unoverlapped tail of the kernel --
+  // with one workgroup per CU every workgroup reaches its epilogue at the same moment.
+  for (int pass = 0; pass < 2; ++pass) {
+    const int u0 = useg0 + (pass ? SG_NU1 : 0);
+    const int nu = pass ? nuseg - SG_NU1 : (nuseg < SG_NU1 ? nuseg : SG_NU1);
+    if (nu <= 0) break;
+    const int R0 = 4 * u0 - DT > 0 ? 4 * u0 - DT : 0;                // region rows [R0, R1) inside the map
+    const int R1 = 4 * (u0 + nu) + DT - 1 < H ? 4 * (u0 + nu) + DT - 1 : H;
+    const int nrows = R1 - R0;
+    const int colL = j0 - DT;                                        // region columns [colL, colL+20): may leave the map
+
+    // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction copies 64 pieces of
+    // 16 bytes from per-lane global addresses into 64 CONSECUTIVE 16-byte LDS slots, no VGPR round
+    // trip.  The LDS image is [channel][row][column group] with a fixed 35-row pitch, so piece e
+    // lands in slot e.  The buffer descriptor covers exactly this batch item's C planes: a piece of a
+    // channel >= C (last chunk) is out of range and arrives as exact zeros.  Columns outside the
+    // map read whatever neighbours them in memory: MFMA columns are independent and those cells are
+    // masked in the epilogue.  Pieces of rows the segment does not have are parked out of range.
+    constexpr int OOR = 0x7ffffff0;                                  // parked byte offset: always out of range
+    int pb_voff[SG_BIW];
+    bool pb_on[SG_BIW];
+#pragma unroll
+    for (int k = 0; k < SG_BIW; ++k) {
+        const int e = (wave + SG_WAVES * k) * 64 + lane;
+        const int ch = e / (SG_ROWS * NCG), rem = e - ch * (SG_ROWS * NCG);
+        const int row = rem / NCG, cg = rem - row * NCG;
+        pb_on[k] = e < SG_NPB;
+        pb_voff[k] = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 : OOR;
+    }
+    int pa_voff = OOR;
+    const bool pa_on = wave < (SG_NPA + 63) / 64;
+    {
+        const int e = wave * 64 + lane;                              // FM0 piece: (channel, pixel row of the segment)
+        const int ch = e / (4 * SG_NU), prow = e - ch * (4 * SG_NU);
+        const int i = 4 * u0 + prow;
+        if (pa_on && e < SG_NPA && i < H) pa_voff = (ch * HW + i * W + j0) * 4;
+    }
+    const int chunk_bytes = SG_KC * HW * 4;
+    auto stage = [&](float* buf, int chunk) {
+        const int cb = chunk * chunk_bytes;
+#pragma unroll
+        for (int k = 0; k < SG_BIW; ++k) {
+            if (pb_on[k]) {
+                const int v = pb_voff[k] == OOR ? OOR : pb_voff[k] + cb;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(buf + (wave + SG_WAVES * k) * 256), 16, v, 0, 0, 0);
+            }
+        }
+        if (pa_on) {
+            const int v = pa_voff == OOR ? OOR : pa_voff + cb;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)(buf + SG_KC * SG_BPL + wave * 256), 16, v, 0, 0, 0);
+        }
+    };
+
+    // ---- this wave's two tasks: id = tile*6 + tile-group
+    int t_tile[2], t_off[2], t_ng[2];
+    bool t_on[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int id = wave + SG_WAVES * k, t = id / 6, T = id - t * 6;
+        const int u = u0 + t;
+        const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;              // tile's window rows inside the map
+        const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
+        const int ng = (wb - wa) * NCG;
+        t_tile[k] = t;
+        t_ng[k] = ng;
+        t_on[k] = t < nu && 16 * T < ng;
+        t_off[k] = ((wa - R0) * NCG + 16 * T) * 4;                   // float offset of the tile-group's first slot
+    }
+    // lane's slot inside the tile-group (clamped to the tile's last group; masked in the epilogue);
+    // a wave without a second task recomputes a valid slot into a dead accumulator: no branch
+    int l_off[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int T = (wave + SG_WAVES * k) % 6;
+        int gi = 16 * T + n;
+        gi = gi < t_ng[k] ? gi : (t_ng[k] > 0 ? t_ng[k] - 1 : 0);
+        l_off[k] = t_on[k] ? t_off[k] - 16 * T * 4 + gi * 4 + g * SG_BPL : g * SG_BPL;
+    }
+    const int a_off0 = SG_KC * SG_BPL + g * SG_APL + (t_on[0] ? t_tile[0] : 0) * 16 + n;
+    const int a_off1 = SG_KC * SG_BPL + g * SG_APL + (t_on[1] ? t_tile[1] : 0) * 16 + n;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[k][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (C + SG_KC - 1) / SG_KC;
+    stage(smem, 0);
+    __syncthreads();                                                 // vmcnt(0) + barrier: chunk 0 has landed
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* cur = smem + (ch & 1) * SG_BUF;
+        stage(smem + ((ch + 1) & 1) * SG_BUF, ch + 1);               // lands during this chunk's MFMAs (past the end: zeros)
+        if (t_on[1]) {                                               // wave-uniform: two tasks (t_on[1] implies t_on[0])
+#pragma unroll
+            for (int ks = 0; ks < SG_KC / 4; ++ks) {
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(cur + l_off[0] + ks * 4 * SG_BPL);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(cur + l_off[1] + ks * 4 * SG_BPL);
+                const float a0 = cur[a_off0 + ks * 4 * SG_APL], a1 = cur[a_off1 + ks * 4 * SG_APL];
+                acc[0][0] = D2T_MFMA(a0, q0.x, acc[0][0]);
+                acc[1][0] = D2T_MFMA(a1, q1.x, acc[1][0]);
+                acc[0][1] = D2T_MFMA(a0, q0.y, acc[0][1]);
+                acc[1][1] = D2T_MFMA(a1, q1.y, acc[1][1]);
+                acc[0][2] = D2T_MFMA(a0, q0.z, acc[0][2]);
+                acc[1][2] = D2T_MFMA(a1, q1.z, acc[1][2]);
+                acc[0][3] = D2T_MFMA(a0, q0.w, acc[0][3]);
+                acc[1][3] = D2T_MFMA(a1, q1.w, acc[1][3]);
+            }
+        } else if (t_on[0]) {                                        // one task
+#pragma unroll
+            for (int ks = 0; ks < SG_KC / 4; ++ks) {
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(cur + l_off[0] + ks * 4 * SG_BPL);
+                const float a0 = cur[a_off0 + ks * 4 * SG_APL];
+                acc[0][0] = D2T_MFMA(a0, q0.x, acc[0][0]);
+                acc[0][1] = D2T_MFMA(a0, q0.y, acc[0][1]);
+                acc[0][2] = D2T_MFMA(a0, q0.z, acc[0][2]);
+                acc[0][3] = D2T_MFMA(a0, q0.w, acc[0][3]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: [nu tiles][16 pixels][17][17] through LDS, then 4*nu contiguous runs ----
+    for (int e = tid; e < nu * 16 * CELLS; e += SG_THREADS) smem[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int T = (wave + SG_WAVES * k) % 6;
+        const int gi = 16 * T + n;
+        if (t_on[k] && gi < t_ng[k]) {
+            const int u = u0 + t_tile[k];
+            const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;
+            const int rho = wa + gi / NCG, cg = gi - (gi / NCG) * NCG;   // displaced row, column group
+            const int ci = rho - (4 * u + g) + DT;                   // di - i + d, pixel row i = 4u + g
+            if (ci >= 0 && ci < 2 * DT) {
+                float* row = smem + (t_tile[k] * 16 + 4 * g) * CELLS + ci * CW;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int dj = colL + 4 * cg + s;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cj = dj - (j0 + r) + DT;
+                        if (cj >= 0 && cj < 2 * DT && dj >= 0 && dj < W) row[r * CELLS + cj] = acc[k][s][r];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 16-byte write-through stores (dword-aligned addresses): a pixel row of the strip is nj*289
+    // contiguous floats in out and starts 16-byte aligned in the LDS image
+    const int nj = W - j0 < TP ? W - j0 : TP;
+    const int run = nj * CELLS, run4 = run >> 2;                     // floats / whole float4s per pixel row
+    const int prs = (H - 4 * u0 < 4 * nu ? H - 4 * u0 : 4 * nu);     // pixel rows that exist
+    for (int e = tid; e < prs * run4; e += SG_THREADS) {
+        const int pr = e / run4, q = e - pr * run4;
+        const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
+                                               ro, off, 0, 16);     // aux 16 = sc1 (write-through)
+    }
+    const int tail = run - 4 * run4;                                 // 0..3 floats per pixel row (nj < 4)
+    for (int e = tid; e < prs * tail; e += SG_THREADS) {
+        const int pr = e / tail, q = 4 * run4 + (e - pr * tail);
+        out[((size_t)b * HW + (4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
+    }
+    __syncthreads();                                                 // LDS image free before the next pass restages
+  }
+}
+
 bool corr_fwd_supported(int B, int C, int H, int W, int d, int s)
 {
     if (d != DT || s != 1 || B < 1 || C < 1 || H < 1 || W < WC) return false;
@@ -382,8 +604,8 @@ int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, i
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     const int nseg = (tiles_i + FS_NU - 1) / FS_NU;
     const long long strip_blocks = 1LL * B * tiles_j * nseg;
-    if (false && strip_blocks >= 192) {              // strip variant disabled: measured slower (register spills), see DESIGN.md
-        hipLaunchKernelGGL(k_corr_fwd_strip, dim3((int)strip_blocks), dim3(FS_THREADS), 0, st,
+    if (strip_blocks >= 192) {                       // enough segments to give (nearly) every CU one
+        hipLaunchKernelGGL(k_corr_fwd_seg, dim3((int)strip_blocks), dim3(SG_THREADS), 0, st,
                            fm0, fm1, out, C, H, W, tiles_i, tiles_j, nseg);
     } else {                                         // small batches: one p-tile per workgroup
         const int blocks = B * tiles_i * tiles_j;
