@@ -16,7 +16,18 @@ import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
-from detect_to_track.models import _ext  # noqa: E402
+from detect_to_track.models import _ext, _native  # noqa: E402
+
+L = _native.lib
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+
+
+def _check(rc):
+    if rc:
+        raise RuntimeError(_native.error_string(rc).decode())
 
 HBM = 8000.0
 
@@ -55,26 +66,39 @@ def main():
             line.update(extra)
         print(json.dumps(line), flush=True)
 
-    # ---- pooling, config 3 and the model-true shapes
+    # ---- pooling, config 3 and the model-true shapes.  Timed through the C ABI with
+    # caller-owned outputs and workspace (what the autograd Function does, minus the allocator).
+    st = torch.cuda.current_stream().cuda_stream
     k = 7
     for name, C, H, W, R in (("roipool", 1024, 38, 63, 300), ("roipool", 1891, 38, 75, 8)):
-        nsets = max(2, int(600e6 // (R * C * k * k * 8 + C * H * W * 8)) + 1)
-        nsets = min(nsets, 8)
+        nsets = min(8, max(2, int(600e6 // (R * C * k * k * 8 + C * H * W * 8)) + 1))
         fm = [torch.rand(C, H, W, device=dev) for _ in range(nsets)]
         go = [torch.rand(R, C, k, k, device=dev) for _ in range(nsets)]
+        out = [torch.empty(R, C, k, k, device=dev) for _ in range(nsets)]
+        gin = [torch.empty(C, H, W, device=dev) for _ in range(nsets)]
         rois = torch.from_numpy(random_rois(R, 0)).to(dev)
+        nf, nbw = L.d2t_roipool_fwd_workspace_bytes(R, C, H, W, k, 4), L.d2t_roipool_bwd_workspace_bytes(R, C, H, W, k, 4)
+        wf, wb = _ws(nf, dev), _ws(nbw, dev)
         nb = R * C * k * k * 4 + C * H * W * 4 + R * 16
-        emit(name, f"R{R}_C{C}_{H}x{W}_k{k}", "fwd", timed(lambda i: _ext.roipool_forward(fm[i], rois, k, args.impl), args.iters, nsets), nb)
-        emit(name, f"R{R}_C{C}_{H}x{W}_k{k}", "bwd", timed(lambda i: _ext.roipool_backward(go[i], rois, H, W, args.impl), args.iters, nsets), nb)
-        del fm, go
+        emit(name, f"R{R}_C{C}_{H}x{W}_k{k}", "fwd", timed(lambda i: _check(L.d2t_roipool_fwd_f32(
+            fm[i].data_ptr(), rois.data_ptr(), out[i].data_ptr(), R, C, H, W, k, wf.data_ptr(), nf, args.impl, st)), args.iters, nsets), nb)
+        emit(name, f"R{R}_C{C}_{H}x{W}_k{k}", "bwd", timed(lambda i: _check(L.d2t_roipool_bwd_f32(
+            go[i].data_ptr(), rois.data_ptr(), gin[i].data_ptr(), R, C, H, W, k, wb.data_ptr(), nbw, args.impl, st)), args.iters, nsets), nb)
+        del fm, go, out, gin
     for nT, H, W, R in ((21, 38, 63, 300), (31, 38, 75, 300), (4, 38, 75, 300), (31, 38, 75, 3000), (4, 38, 75, 3000)):
         C = nT * k * k
         fm = [torch.rand(C, H, W, device=dev) for _ in range(4)]
         go = [torch.rand(R, nT, k, k, device=dev) for _ in range(4)]
+        out = [torch.empty(R, nT, k, k, device=dev) for _ in range(4)]
+        gin = [torch.empty(C, H, W, device=dev) for _ in range(4)]
         rois = torch.from_numpy(random_rois(R, 1)).to(dev)
+        nbw = L.d2t_psroipool_bwd_workspace_bytes(R, nT, H, W, k, 4)
+        wb = _ws(nbw, dev)
         nb = R * nT * k * k * 4 + C * H * W * 4 + R * 16
-        emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "fwd", timed(lambda i: _ext.ps_roipool_forward(fm[i], rois, nT, k, args.impl), args.iters, 4), nb)
-        emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "bwd", timed(lambda i: _ext.ps_roipool_backward(go[i], rois, H, W, args.impl), args.iters, 4), nb)
+        emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "fwd", timed(lambda i: _check(L.d2t_psroipool_fwd_f32(
+            fm[i].data_ptr(), rois.data_ptr(), out[i].data_ptr(), R, nT, H, W, k, 0, 0, args.impl, st)), args.iters, 4), nb)
+        emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "bwd", timed(lambda i: _check(L.d2t_psroipool_bwd_f32(
+            go[i].data_ptr(), rois.data_ptr(), gin[i].data_ptr(), R, nT, H, W, k, wb.data_ptr(), nbw, args.impl, st)), args.iters, 4), nb)
 
     # ---- correlation: metric shape, config 2, model-true shapes
     for B, C, H, W in ((8, 256, 38, 63), (1, 256, 38, 63), (1, 512, 38, 75), (1, 1024, 38, 75), (1, 2048, 38, 75)):
@@ -85,11 +109,17 @@ def main():
         go = [torch.rand(B, H, W, 17, 17, device=dev) for _ in range(nsets)]
         inb, outb = B * C * H * W * 4, B * H * W * 289 * 4
         vox = B * H * W * 289
-        tf = timed(lambda i: _ext.pointwise_correlation_forward(f0[i], f1[i], d, 1, args.impl), args.iters, nsets)
-        tb = timed(lambda i: _ext.pointwise_correlation_backward(go[i], f0[i], f1[i], d, 1, args.impl), args.iters, nsets)
+        out = [torch.empty(B, H, W, 17, 17, device=dev) for _ in range(nsets)]
+        g0 = [torch.empty(B, C, H, W, device=dev) for _ in range(nsets)]
+        g1 = [torch.empty(B, C, H, W, device=dev) for _ in range(nsets)]
+        tf = timed(lambda i: _check(L.d2t_corr_fwd_f32(f0[i].data_ptr(), f1[i].data_ptr(), out[i].data_ptr(),
+                                                        B, C, H, W, d, 1, 0, 0, args.impl, st)), args.iters, nsets)
+        tb = timed(lambda i: _check(L.d2t_corr_bwd_f32(go[i].data_ptr(), f0[i].data_ptr(), f1[i].data_ptr(),
+                                                        g0[i].data_ptr(), g1[i].data_ptr(),
+                                                        B, C, H, W, d, 1, 0, 0, args.impl, st)), args.iters, nsets)
         emit("corr", f"B{B}_C{C}_{H}x{W}_d8", "fwd", tf, 2 * inb + outb, dict(gvox_s=round(vox / tf / 1e3, 2)))
         emit("corr", f"B{B}_C{C}_{H}x{W}_d8", "bwd", tb, outb + 4 * inb, dict(gvox_s=round(vox / tb / 1e3, 2)))
-        del f0, f1, go
+        del f0, f1, go, out, g0, g1
 
 
 if __name__ == "__main__":

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(RF_THREADS)
 k_roipool_fwd_cl(const float* __restrict__ fmt, const int32_t* __restrict__ geo, float* __restrict__ out,
                  int C, int W)
 {
-    __shared__ float stage[64 * KK + 16];                            // 12.6 KB
+    __shared__ __attribute__((aligned(16))) float stage[64 * KK + 16];   // 12.6 KB
     const int lane = threadIdx.x & 63;
     const int i = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index = bin row (wave-uniform)
     const int r = blockIdx.x, c0 = blockIdx.y * 64;
@@ -146,9 +146,17 @@ k_roipool_fwd_cl(const float* __restrict__ fmt, const int32_t* __restrict__ geo,
         stage[lane * KK + i * KT + j] = acc[j] / static_cast<float>(n);     // 0/0 = NaN as the reference
     }
     __syncthreads();
+    // the workgroup's 64 x 49 block is one contiguous, 16-byte aligned run of out: 16-byte
+    // WRITE-THROUGH stores (sc1), so the 60 MB of output drain to HBM while other workgroups still
+    // pool instead of sitting dirty in L2 until the kernel ends
     const int nch = C - c0 < 64 ? C - c0 : 64;
     float* dst = out + ((size_t)r * C + c0) * KK;
-    for (int e = threadIdx.x; e < nch * KK; e += RF_THREADS) dst[e] = stage[e];
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (unsigned)nch * KK * 4u, 0x00020000);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int n4 = (nch * KK) >> 2;
+    for (int e = threadIdx.x; e < n4; e += RF_THREADS)
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(stage + 4 * e), ro, e * 16, 0, 16);
+    for (int e = 4 * n4 + threadIdx.x; e < nch * KK; e += RF_THREADS) dst[e] = stage[e];
 }
 
 bool roipool_fwd_supported(int R, int C, int H, int W, int k)
