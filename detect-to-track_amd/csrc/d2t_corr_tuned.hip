@@ -385,13 +385,15 @@ constexpr int SG_WAVES = 15;                        // 30 (tile, tile-group) tas
 constexpr int SG_THREADS = SG_WAVES * 64;
 constexpr int SG_KC = 16;                           // channels per staged chunk (4 k-steps)
 constexpr int SG_ROWS = 4 * SG_NU + 2 * DT - 1;     // 35 window rows of a segment
-constexpr int SG_BPL = SG_ROWS * WC;                // 700 floats: FM1 region of one channel
+constexpr int SG_SLOTS = SG_ROWS * NCG + 1;         // 176 slots of 16 bytes per channel (175 pieces + 1 pad)
+constexpr int SG_BPL = SG_SLOTS * 4;                // 704 floats: plane stride = 0 mod 64 dwords -> the four
+                                                    // k-slot lane groups of a ds_read_b128 hit disjoint banks
 constexpr int SG_APL = SG_NU * 16;                  // 80 floats: FM0 pixels of one channel
 constexpr int SG_BUF = SG_KC * (SG_BPL + SG_APL);   // floats per buffer (48.75 KB)
 constexpr int SG_STAGE = SG_NU * 16 * CELLS;        // out staging (90.3 KB), aliases the buffers
 constexpr int SG_LDS = 2 * SG_BUF > SG_STAGE ? 2 * SG_BUF : SG_STAGE;
 
-constexpr int SG_NPB = SG_KC * SG_ROWS * NCG;       // 2800 FM1 pieces (16 bytes) per chunk
+constexpr int SG_NPB = SG_KC * SG_SLOTS;            // 2816 FM1 slots (16 bytes) per chunk = 44 wave-instructions
 constexpr int SG_NPA = SG_KC * 4 * SG_NU;           // 320 FM0 pieces per chunk
 constexpr int SG_BI = (SG_NPB + 63) / 64;           // 44 wave-instructions move the FM1 region of a chunk
 constexpr int SG_BIW = (SG_BI + SG_WAVES - 1) / SG_WAVES;   // 3 per wave
@@ -443,7 +445,7 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
 #pragma unroll
     for (int k = 0; k < SG_BIW; ++k) {
         const int e = (wave + SG_WAVES * k) * 64 + lane;
-        const int ch = e / (SG_ROWS * NCG), rem = e - ch * (SG_ROWS * NCG);
+        const int ch = e / SG_SLOTS, rem = e - ch * SG_SLOTS;        // slot rem of channel ch (slot 175: pad)
         const int row = rem / NCG, cg = rem - row * NCG;
         pb_on[k] = e < SG_NPB;
         pb_voff[k] = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 : OOR;
