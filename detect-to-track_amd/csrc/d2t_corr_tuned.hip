@@ -797,11 +797,111 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
     store_tile(acc[1], tiles_i - 1);
 }
 
+// The same kernel with the workgroup width as a template parameter (instantiated for 4 waves = 64
+// channels), used when 16-wave workgroups would leave most CUs idle (B = 1 shapes of the real
+// model).  Kept separate from the 16-wave kernel above, whose code generation it perturbs (+6 %).
+template <int ST_WAVES>
+__global__ void __launch_bounds__(ST_WAVES * 64)
+k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
+                 float* __restrict__ g0, float* __restrict__ g1,
+                 int B, int C, int H, int W, int tiles_i, int tiles_j)
+{
+    constexpr int ST_THREADS = ST_WAVES * 64;
+    constexpr int ST_CH = ST_WAVES * 16;                             // channels per workgroup pass
+    constexpr int Q_PER_THREAD = 2048 / ST_THREADS;                  // ring quads per thread (2 or 8)
+    __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 64 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // (role, b) pairs stay on one XCD
+    const int tj = bid % tiles_j, b = (bid / tiles_j) % B, role = bid / (tiles_j * B);
+    const int j0 = tj * TP, HW = H * W;
+    const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
+    const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
+    const float* S = role ? fm0 : fm1;
+    float* gx = role ? g1 : g0;
+    const float* gb = gout + (size_t)b * HW * CELLS;
+
+    const int cw = blockIdx.y * ST_CH + wave * 16;                   // first channel of this wave's c-tile
+    const int cl = cw + n < C ? cw + n : C - 1;                      // lane's channel (clamped; never stored)
+    const float* sp = S + ((size_t)b * C + cl) * HW + col0;
+
+    f32x4 acc[NACT];
+#pragma unroll
+    for (int a = 0; a < NACT; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // S fragment of k-block 5*ss + q: group 20*ss + 4q + g.  Rows past the map carry G = 0.
+    auto s_load = [&](int ss, int q) -> f32x4 {
+        const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
+        int rho = 4 * ss + xr;
+        rho = rho < H ? rho : H - 1;
+        return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
+    };
+    auto store_tile = [&](const f32x4& d, int u) {
+        const int i = 4 * u + (n >> 2), j = j0 + (n & 3);
+        if (u < 0 || u >= tiles_i || i >= H || j >= W) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = cw + 4 * g + r;
+            if (c < C) gx[((size_t)b * C + c) * HW + i * W + j] = d[r];
+        }
+    };
+    // the two ring quads this thread produces every super-step (slots >= 1600 are padding: mask 0)
+    QuadDesc qd[Q_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < Q_PER_THREAD; ++k) qd[k] = strip_quad_desc(role, tid + k * ST_THREADS, H, W, tiles_i, j0, col0);
+    const int gstep = 4 * W * CELLS;                                  // gradOut offset of 4 map rows
+    const int gdp = role ? CELLS - 1 : 1;
+
+    // prologue: ring[0] <- super-step 0, registers <- super-step 1
+    f32x4 gn[Q_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < Q_PER_THREAD; ++k)
+        reinterpret_cast<f32x4*>(ring[0])[tid + k * ST_THREADS] = strip_quad_load(gb, qd[k], 0, gstep, gdp);
+#pragma unroll
+    for (int k = 0; k < Q_PER_THREAD; ++k) gn[k] = strip_quad_load(gb, qd[k], 1, gstep, gdp);
+    f32x4 av = s_load(0, 0);
+    __syncthreads();
+
+    // The loop body is straight-line code (no branches): every load is unconditional, so the
+    // compiler can retire them with counted s_waitcnt instead of draining at block boundaries.
+    for (int ss = 0; ss < tiles_i; ++ss) {
+        const int cur = ss & 1;
+        const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
+#pragma unroll
+        for (int q = 0; q < KB_SS; ++q) {
+            const f32x4 a4 = av;
+            av = q + 1 < KB_SS ? s_load(ss, q + 1) : s_load(ss + 1, 0);
+            f32x4 bv[NACT];
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                            // s outer: 5 independent accumulators
+#pragma unroll
+                for (int a = 0; a < NACT; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
+            }
+        }
+        // hand super-step ss+1's G (requested a whole super-step ago) to the other buffer, then
+        // request ss+2's: these loads are the YOUNGEST in the queue, so no FM load of the next
+        // super-step has to wait behind them (vmcnt retires in order)
+#pragma unroll
+        for (int k = 0; k < Q_PER_THREAD; ++k) reinterpret_cast<f32x4*>(ring[cur ^ 1])[tid + k * ST_THREADS] = gn[k];
+#pragma unroll
+        for (int k = 0; k < Q_PER_THREAD; ++k) gn[k] = strip_quad_load(gb, qd[k], ss + 2, gstep, gdp);   // past the map: zeros
+        __syncthreads();
+        store_tile(acc[0], ss - 2);                                  // complete after its 5th super-step
+#pragma unroll
+        for (int a = 0; a + 1 < NACT; ++a) acc[a] = acc[a + 1];
+        acc[NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    store_tile(acc[0], tiles_i - 2);                                 // their remaining super-steps lie below the map
+    store_tile(acc[1], tiles_i - 1);
+}
+
 bool corr_bwd_supported(int B, int C, int H, int W, int d, int s)
 {
     if (d != DT || s != 1 || B < 1 || C < 1 || H < 1 || W < WC) return false;
     const long long blocks = 2LL * B * ((W + TP - 1) / TP);
-    return blocks <= 0x7fffffffLL && (C + ST_CH - 1) / ST_CH <= 65535;
+    return blocks <= 0x7fffffffLL && (C + 63) / 64 <= 65535;
 }
 
 size_t corr_bwd_ws_bytes(int, int, int, int, int, int) { return 0; }
@@ -810,8 +910,13 @@ int corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g
                  int B, int C, int H, int W, int, int, void*, hipStream_t st)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
-    hipLaunchKernelGGL(k_corr_bwd_strip, dim3(2 * B * tiles_j, (C + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
-                       gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    const long long wide = 2LL * B * tiles_j * ((C + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
+    if (wide >= 100)
+        hipLaunchKernelGGL(k_corr_bwd_strip, dim3(2 * B * tiles_j, (C + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
+                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    else                                                             // small grids: 4 waves (64 channels) per workgroup
+        hipLaunchKernelGGL(k_corr_bwd_strip_n<4>, dim3(2 * B * tiles_j, (C + 63) / 64), dim3(256), 0, st,
+                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
     return launch_status();
 }
 
