@@ -355,21 +355,48 @@ k_psroipool_bwd_plane(const float* __restrict__ gout, const int32_t* __restrict_
     }
 }
 
-// phase 2: gin[ch] = sum of the planes (t, bin) with (t+1)*bin == ch, ascending bin then t;
-// channels nothing maps to are zero.
+// The planes that map to an input channel: (t+1)*bin == ch, i.e. bin | ch with ch/bin <= nT
+// (ps_roipool_cuda.cu:58); channel 0 collects bin 0 of every t.  One small kernel inverts the map
+// once per call: src[ch][0..PS_MAXSRC) = plane indices in ascending (bin, t) order, -1 terminated.
+constexpr int PS_MAXSRC = 48;                       // >= max(nT for ch 0 capped, divisors <= 48 of ch)
+
+__global__ void __launch_bounds__(64)
+k_psroipool_invert_map(int32_t* __restrict__ src, int nT)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= nT * KK) return;
+    int32_t* d = src + (size_t)ch * PS_MAXSRC;
+    int m = 0;
+    if (ch == 0) {
+        // bin 0 of every target maps to channel 0; nT may exceed the table: phase 2 handles ch 0 itself
+        d[0] = -1;
+        return;
+    }
+    for (int bin = 1; bin < KK; ++bin) {
+        if (ch % bin != 0) continue;
+        const int tp1 = ch / bin;
+        if (tp1 <= nT && m < PS_MAXSRC - 1) d[m++] = (tp1 - 1) * KK + bin;
+    }
+    d[m] = -1;
+}
+
+// phase 2: gin[ch] = sum of the planes that map to ch, ascending bin then t; channels nothing
+// maps to are zero.
 __global__ void __launch_bounds__(256)
-k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, int nT, int HW)
+k_psroipool_bwd_gather(const float* __restrict__ part, const int32_t* __restrict__ src, float* __restrict__ gin,
+                       int nT, int HW)
 {
     const int ch = blockIdx.y;
+    const int32_t* sl = src + (size_t)ch * PS_MAXSRC;                // wave-uniform
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
         float a = 0.f;
         if (ch == 0) {
             for (int t = 0; t < nT; ++t) a += part[(size_t)(t * KK) * HW + p];
         } else {
-            for (int bin = 1; bin < KK; ++bin) {
-                if (ch % bin != 0) continue;
-                const int tp1 = ch / bin;
-                if (tp1 <= nT) a += part[(size_t)((tp1 - 1) * KK + bin) * HW + p];
+            for (int k = 0; k < PS_MAXSRC; ++k) {
+                const int pl = sl[k];
+                if (pl < 0) break;
+                a += part[(size_t)pl * HW + p];
             }
         }
         gin[(size_t)ch * HW + p] = a;
@@ -384,7 +411,8 @@ bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
 size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
 {
     if (!psroipool_bwd_supported(R, nT, H, W, k)) return 0;
-    return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float));
+    return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float)) +
+           align256((size_t)nT * KK * PS_MAXSRC * sizeof(int32_t));
 }
 
 int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
@@ -392,7 +420,12 @@ int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, i
 {
     int32_t* cells = static_cast<int32_t*>(ws);
     float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + bins_bytes(R));
+    int32_t* src = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + bins_bytes(R) +
+                                              align256((size_t)nT * KK * H * W * sizeof(float)));
     int rc = psroipool_bins<float>(rois, cells, R, H, W, k, st);
+    if (rc != D2T_OK) return rc;
+    hipLaunchKernelGGL(k_psroipool_invert_map, dim3((nT * KK + 63) / 64), dim3(64), 0, st, src, nT);
+    rc = launch_status();
     if (rc != D2T_OK) return rc;
     if (H <= 40)
         hipLaunchKernelGGL(k_psroipool_bwd_plane<10>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
@@ -401,7 +434,7 @@ int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, i
     rc = launch_status();
     if (rc != D2T_OK) return rc;
     const int HW = H * W;
-    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, src, gin, nT, HW);
     return launch_status();
 }
 
