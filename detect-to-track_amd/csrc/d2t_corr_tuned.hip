@@ -183,191 +183,6 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
 }
 
 // ------------------------------------------------------------------------------------
-// Forward, column-strip variant (used when the grid is large enough to fill the chip).
-// One workgroup owns a segment of up to 5 vertically stacked p-tiles (20 x 4 pixels).  The union
-// of their windows (<= 35 rows x 20 columns) is enumerated once in groups of 4 columns; wave T owns
-// tile-group T (16 groups) and keeps accumulators for EVERY p-tile of the segment whose window
-// meets its rows (<= 5): one 16-byte FM1 load per lane per k-step now feeds up to 20 MFMAs, and
-// every FM1 byte is fetched once per segment instead of once per p-tile (the tile kernel above
-// measured L2-request-bound: ~450 MB of partial-line reads per call).  The FM0 tiles of the
-// segment are staged per 64 channels in a double-buffered LDS image shared by all waves.
-// Arithmetic is unchanged: the same ascending-channel MFMA chain per output, bit-identical.
-// ------------------------------------------------------------------------------------
-constexpr int FS_NU = 5;                            // p-tiles per segment
-constexpr int FS_WAVES = 12;                        // >= ceil((4*FS_NU + 15) * NCG / 16) = 11 tile-groups
-constexpr int FS_THREADS = FS_WAVES * 64;
-constexpr int FS_APIX = FS_NU * 16;                 // staged FM0 floats per channel
-constexpr int FS_STAGE = FS_NU * 16 * CELLS;        // out staging floats (92.5 KB), aliases the FM0 buffers
-static_assert(FS_STAGE >= 2 * ACH * FS_APIX, "out staging must cover both FM0 buffers");
-
-// FM1 group of k-step ks for this lane (channel 4*ks + g; clamped to an existing channel, the value
-// is replaced by exact zeros at the point of use when the channel does not exist).
-__device__ __forceinline__ f32x4 fs_load(const float* __restrict__ bp, int ks, int g, int C, int HW)
-{
-    int c = 4 * ks + g;
-    c = c < C ? c : C - 1;
-    return *reinterpret_cast<const f32x4u*>(bp + (size_t)(c - g) * HW);
-}
-
-// 16 k-steps of one FM0 chunk for a wave with CNT live p-tiles.  The FM1 loads run two k-steps
-// ahead of the MFMAs that consume them (qa/qb carry across chunks); the body is straight-line.
-template <int CNT>
-__device__ __forceinline__ void fs_chunk(f32x4 (&acc)[FS_NU][4], f32x4& qa, f32x4& qb,
-                                         const float* __restrict__ abuf, const float* __restrict__ bp,
-                                         int k0, int g, int C, int HW)
-{
-#define D2T_FS_STEP(Q, KK)                                                                      \
-    {                                                                                           \
-        const f32x4 q_ = (4 * (k0 + (KK)) + g < C) ? (Q) : f32x4{0.f, 0.f, 0.f, 0.f};           \
-        const float* ar_ = abuf + ((KK) * 4 + g) * FS_APIX;                                     \
-        _Pragma("unroll") for (int t = 0; t < CNT; ++t) {                                       \
-            const float a_ = ar_[t * 16];                                                       \
-            acc[t][0] = D2T_MFMA(a_, q_.x, acc[t][0]);                                          \
-            acc[t][1] = D2T_MFMA(a_, q_.y, acc[t][1]);                                          \
-            acc[t][2] = D2T_MFMA(a_, q_.z, acc[t][2]);                                          \
-            acc[t][3] = D2T_MFMA(a_, q_.w, acc[t][3]);                                          \
-        }                                                                                       \
-    }
-#pragma unroll 1
-    for (int kk = 0; kk < ACH / 4; kk += 2) {
-        const f32x4 q0 = qa;
-        qa = fs_load(bp, k0 + kk + 2, g, C, HW);
-        D2T_FS_STEP(q0, kk);
-        const f32x4 q1 = qb;
-        qb = fs_load(bp, k0 + kk + 3, g, C, HW);
-        D2T_FS_STEP(q1, kk + 1);
-    }
-#undef D2T_FS_STEP
-}
-
-__global__ void __launch_bounds__(FS_THREADS)
-k_corr_fwd_strip(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
-                 int C, int H, int W, int tiles_i, int tiles_j, int nseg)
-{
-    __shared__ __attribute__((aligned(16))) float smem[FS_STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
-    const int u0 = seg * FS_NU, nu = tiles_i - u0 < FS_NU ? tiles_i - u0 : FS_NU;
-    const int j0 = tj * TP, HW = H * W;
-
-    // window rows of the segment that exist in the map, clamped column origin
-    const int R0 = 4 * u0 - DT > 0 ? 4 * u0 - DT : 0;
-    const int R1 = 4 * (u0 + nu) + DT - 1 < H ? 4 * (u0 + nu) + DT - 1 : H;
-    const int NG = (R1 - R0) * NCG, NT = (NG + 15) >> 4;
-    int col0 = j0 - DT;
-    col0 = col0 < 0 ? 0 : (col0 > W - WC ? W - WC : col0);
-
-    // this lane's column group; the wave's rows; the p-tiles whose windows meet them
-    const int gsel = 16 * wave + n;
-    const int gi = gsel < NG ? gsel : NG - 1;
-    const int rho = R0 + gi / NCG, cg = gi - (gi / NCG) * NCG;
-    const bool active = wave < NT;
-    const int ga = 16 * wave < NG ? 16 * wave : NG - 1, gb = 16 * wave + 15 < NG ? 16 * wave + 15 : NG - 1;
-    const int rho_a = R0 + ga / NCG, rho_b = R0 + gb / NCG;           // wave-uniform
-    int ua = (rho_a - (2 * DT + TP - 2) + 3 + 4096) / 4 - 1024;       // ceil((rho_a - 10) / 4), also for negatives
-    int ub = (rho_b + DT) / 4;                                         // floor((rho_b + 8) / 4)
-    ua = ua < u0 ? u0 : ua;
-    ub = ub > u0 + nu - 1 ? u0 + nu - 1 : ub;
-    const int cnt = active && ub >= ua ? ub - ua + 1 : 0;             // 0..5, wave-uniform
-    const float* bp = fm1 + (size_t)b * C * HW + g * HW + rho * W + col0 + 4 * cg;
-
-    // FM0 staging: piece e = (channel, pixel row of the segment): 4 pixels = 16 bytes
-    const int aj = j0 + TP <= W ? j0 : W - TP;                         // stay inside the row at the right edge
-    const int ashift = j0 - aj;
-    const float* a_base = fm0 + (size_t)b * C * HW + aj;
-    auto a_fetch = [&](int chunk, int e) -> f32x4 {
-        const int ch = e / (4 * FS_NU), row = e - ch * (4 * FS_NU);
-        int c = chunk * ACH + ch;
-        c = c < C ? c : C - 1;
-        int i = 4 * u0 + row;
-        i = i < H ? i : H - 1;
-        return *reinterpret_cast<const f32x4u*>(a_base + (size_t)c * HW + i * W);
-    };
-    auto a_put = [&](float* buf, f32x4 v, int chunk, int e) {
-        const int ch = e / (4 * FS_NU), row = e - ch * (4 * FS_NU);
-        const bool live = chunk * ACH + ch < C;
-        f32x4 w;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int src = k + ashift < 4 ? k + ashift : 3;
-            w[k] = live ? v[src] : 0.f;
-        }
-        *reinterpret_cast<f32x4*>(buf + ch * FS_APIX + row * 4) = w;   // [ch][tile = row/4][pixel = (row%4)*4 + k]
-    };
-    constexpr int NPIECE = ACH * 4 * FS_NU;                            // 1280 pieces per chunk
-    const int e0 = tid, e1 = tid + FS_THREADS;                         // every thread moves e0; some also e1
-    const bool has1 = e1 < NPIECE;
-
-    f32x4 acc[FS_NU][4];
-#pragma unroll
-    for (int t = 0; t < FS_NU; ++t)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[t][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = (C + ACH - 1) / ACH;
-    f32x4 qa = fs_load(bp, 0, g, C, HW), qb = fs_load(bp, 1, g, C, HW);
-    a_put(smem, a_fetch(0, e0), 0, e0);
-    if (has1) a_put(smem, a_fetch(0, e1), 0, e1);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* cur = smem + (ch & 1) * ACH * FS_APIX;
-        const int nx = ch + 1 < nchunks ? ch + 1 : ch;
-        const f32x4 an0 = a_fetch(nx, e0);
-        const f32x4 an1 = has1 ? a_fetch(nx, e1) : an0;
-        const float* ab = cur + (ua - u0) * 16 + n;                    // first active tile, this lane's pixel
-        switch (cnt) {                                                 // wave-uniform; bodies are straight-line
-            case 1: fs_chunk<1>(acc, qa, qb, ab, bp, ch * (ACH / 4), g, C, HW); break;
-            case 2: fs_chunk<2>(acc, qa, qb, ab, bp, ch * (ACH / 4), g, C, HW); break;
-            case 3: fs_chunk<3>(acc, qa, qb, ab, bp, ch * (ACH / 4), g, C, HW); break;
-            case 4: fs_chunk<4>(acc, qa, qb, ab, bp, ch * (ACH / 4), g, C, HW); break;
-            case 5: fs_chunk<5>(acc, qa, qb, ab, bp, ch * (ACH / 4), g, C, HW); break;
-            default: break;
-        }
-        float* nxt = smem + ((ch + 1) & 1) * ACH * FS_APIX;
-        a_put(nxt, an0, ch + 1, e0);
-        if (has1) a_put(nxt, an1, ch + 1, e1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: [nu tiles][16 pixels][17][17] through LDS, then 4*nu contiguous runs ----
-    for (int e = tid; e < nu * 16 * CELLS; e += FS_THREADS) smem[e] = 0.f;
-    __syncthreads();
-    if (gsel < NG) {
-#pragma unroll
-        for (int t = 0; t < FS_NU; ++t) {
-            if (t < cnt) {
-                const int u = ua + t;
-                const int ci = rho - (4 * u + g) + DT;                 // di - i + d, pixel row i = 4u + g
-                if (ci >= 0 && ci < 2 * DT) {
-                    float* row = smem + ((u - u0) * 16 + 4 * g) * CELLS + ci * CW;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int cj = col0 + 4 * cg + s - (j0 + r) + DT;
-                            if (cj >= 0 && cj < 2 * DT) row[r * CELLS + cj] = acc[t][s][r];
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int nj = W - j0 < TP ? W - j0 : TP;
-    const int run = nj * CELLS;                                        // floats per pixel row of the strip
-    for (int pr = 0; pr < 4 * nu; ++pr) {
-        const int i = 4 * u0 + pr;
-        if (i >= H) break;
-        float* dst = out + (((size_t)b * H + i) * W + j0) * CELLS;
-        const float* src = smem + (size_t)pr * 4 * CELLS;              // tile pr/4, pixels (pr%4)*4 ..
-        for (int e = tid; e < run; e += FS_THREADS) dst[e] = src[e];
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // Forward, LDS-staged segment kernel (the default when the grid fills the chip).
 // The tile kernel above gathers every p-tile's 19 x 20 window straight from L2 in 80-byte row
 // pieces; rocprofv3 shows its texture-address unit 85 % busy (TA_TA_BUSY) at ~25 useful bytes per
@@ -604,7 +419,7 @@ int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, i
                  void*, hipStream_t st)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
-    const int nseg = (tiles_i + FS_NU - 1) / FS_NU;
+    const int nseg = (tiles_i + SG_NU - 1) / SG_NU;
     const long long strip_blocks = 1LL * B * tiles_j * nseg;
     if (strip_blocks >= 192) {                       // enough segments to give (nearly) every CU one
         hipLaunchKernelGGL(k_corr_fwd_seg, dim3((int)strip_blocks), dim3(SG_THREADS), 0, st,
