@@ -10,18 +10,21 @@
 //
 // Tiling.  M = 16 pixels p arranged 4x4 (a "p-tile"); their windows' union is 19 rows x 19
 // columns of FM1.  That union is enumerated as groups of 4 consecutive columns (5 groups = 20
-// columns per row, origin clamped so that all 20 columns lie inside the map): one lane loads one
-// group with ONE 16-byte global load and feeds FOUR MFMAs (four N-tiles) with it.  16 groups x 4
-// columns = one "tile-group" = 4 N-tiles of 16 columns, owned by one wave; a p-tile has at most
-// 6 tile-groups (95 groups), rows of the window that fall outside the map are not enumerated at
-// all.  K = channels, 4 per MFMA, ascending.  No LDS on the streamed operand: every FM1 element
-// is used by exactly one MFMA of one wave.  The 16 x C FM0 tile is shared by the waves through
-// LDS.  The epilogue stages the p-tile's 16 x 17 x 17 outputs (including the structural zeros
-// the reference gets from at::zeros, :192) in LDS and writes 4 contiguous runs of 4 x 289 floats.
+// columns per row): one 16-byte piece is one lane's B operand of FOUR MFMAs (four N-tiles).
+// 16 groups x 4 columns = one "tile-group" = 4 N-tiles of 16 columns = one wave task; a p-tile has
+// at most 6 tile-groups (95 groups), rows of the window that fall outside the map are not
+// enumerated at all.  K = channels, 4 per MFMA, ascending.
 //
-// One workgroup = one p-tile = 6 waves.  At B=8, 38x63 that is 1280 workgroups = 5 per CU, all
-// resident at once; the XCD-aware block map puts a whole batch item (160 tiles) on one XCD so
-// that its FM0/FM1 planes stream through that XCD's L2 once.
+// Forward kernels (all bit-identical): workgroups own SEGMENTS of vertically stacked p-tiles and
+// copy the union of their windows into LDS by LDS-DMA, 16 channels at a time --
+//   k_corr_fwd_seg        5 tiles / 15 waves, two staged chunks   (grids >= 192 segments: B = 8)
+//   k_corr_fwd_segx<2,4>  2 tiles /  6 waves, ring of 4 chunks    (medium grids)
+//   k_corr_fwd_segx<1,4>  1 tile  /  3 waves, ring of 4 chunks    (the real model's B = 1 pairs)
+// The epilogue stages the segment's outputs (including the structural zeros the reference gets
+// from at::zeros, :192) in LDS and stores contiguous runs with write-through stores.  The XCD-aware
+// block map gives every XCD a contiguous run of segments so that neighbours share L2 lines.
+// The first generation (one p-tile per workgroup, FM1 gathered straight from L2) measured
+// texture-address-bound and is gone; DESIGN.md section 4.2 keeps its numbers.
 #include "d2t_tuned.hpp"
 
 namespace d2t { namespace tuned {
@@ -38,8 +41,6 @@ constexpr int NCG = (WR + 3) / 4;          // 5 column groups per window row
 constexpr int WC = NCG * 4;                // 20 loaded columns
 constexpr int CW = 2 * DT + 1;             // 17
 constexpr int CELLS = CW * CW;             // 289
-constexpr int FWD_WAVES = 6;               // >= max tile-groups = ceil(19*5/16)
-constexpr int FWD_THREADS = FWD_WAVES * 64;
 
 // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of logical tiles
 // (bijective for any grid size).  Placement only affects L2 reuse, never results.
@@ -48,144 +49,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-constexpr int ACH = 64;                    // FM0 channels per staged chunk (16 k-steps)
-
-__global__ void __launch_bounds__(FWD_THREADS, 8)      // 8 waves/SIMD: 5 workgroups (30 waves) per CU
-k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
-                int C, int H, int W, int tiles_i, int tiles_j)
-{
-    // 18.5 KB: two FM0 chunk buffers [ACH][16] (8 KB) during the main loop, then the out tile
-    __shared__ __attribute__((aligned(16))) float smem[16 * CELLS];
-    static_assert(16 * CELLS >= 2 * ACH * 16, "out tile must cover the FM0 staging buffers");
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tj = bid % tiles_j, ti = (bid / tiles_j) % tiles_i, b = bid / (tiles_j * tiles_i);
-    const int i0 = ti * TP, j0 = tj * TP;
-    const int HW = H * W;
-
-    // window rows that exist in the map, and the clamped column origin (all 20 columns in-map)
-    const int wr_lo = DT - i0 > 0 ? DT - i0 : 0;
-    const int wr_hi = H + DT - i0 < WR ? H + DT - i0 : WR;
-    const int NG = (wr_hi - wr_lo) * NCG;              // enumerated column groups
-    const int ntg = (NG + 15) >> 4;                    // tile-groups (<= FWD_WAVES)
-    int col0 = j0 - DT;
-    col0 = col0 < 0 ? 0 : (col0 > W - WC ? W - WC : col0);
-
-    // this lane's column group (clamped for the load; masked in the epilogue)
-    const int gsel = 16 * wave + n;
-    const int gi = gsel < NG ? gsel : NG - 1;
-    const int wr = wr_lo + gi / NCG;
-    const int di = i0 - DT + wr;
-    const int djs = col0 + 4 * (gi % NCG);
-    const float* bp = fm1 + (size_t)b * C * HW + g * HW + di * W + djs;   // channel g of k-step 0
-
-    // FM0 staging: threads 0..255 each move one row (4 pixels, 16 bytes) of one channel per chunk.
-    // Pixels of partial tiles are clamped into the map (their outputs are never stored).
-    const int sch = tid >> 2, srow = tid & 3;
-    const int ai = i0 + srow < H ? i0 + srow : H - 1;
-    const int aj = j0 + TP <= W ? j0 : W - TP;          // shift left at the right edge: stay in the row
-    const int ashift = j0 - aj;                         // 0..3 pixels to rotate back
-    const float* ap = fm0 + (size_t)b * C * HW + ai * W + aj;
-    auto a_fetch = [&](int chunk) -> f32x4 {
-        int c = chunk * ACH + sch;
-        c = c < C ? c : C - 1;                          // clamped, zeroed below
-        return *reinterpret_cast<const f32x4u*>(ap + (size_t)c * HW);
-    };
-    auto a_put = [&](float* buf, f32x4 v, int chunk) {
-        if (tid < 4 * ACH) {
-            const bool live = chunk * ACH + sch < C;    // channels past C feed exact zeros
-            f32x4 w;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {               // pixel j0+k lives at v[k + ashift] (clamped dup beyond W)
-                const int src = k + ashift < 4 ? k + ashift : 3;
-                w[k] = live ? v[src] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(buf + sch * 16 + srow * 4) = w;
-        }
-    };
-
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    const bool active = wave < ntg;
-    const int nchunks = (C + ACH - 1) / ACH;
-
-    // FM1 group of k-step ks for this lane: channel clamped to an existing one, the value is replaced
-    // by exact zeros at the point of use when the channel does not exist
-    auto t_load = [&](int ks) -> f32x4 {
-        int c = 4 * ks + g;
-        c = c < C ? c : C - 1;
-        return *reinterpret_cast<const f32x4u*>(bp + (size_t)(c - g) * HW);
-    };
-    f32x4 qa = t_load(0), qb = t_load(1), qc = t_load(2), qd = t_load(3);
-
-    a_put(smem, a_fetch(0), 0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        float* cur = smem + (ch & 1) * ACH * 16;
-        const f32x4 anext = a_fetch(ch + 1 < nchunks ? ch + 1 : ch);     // lands during this chunk's MFMAs
-        if (active) {
-            // Straight-line body: every load is unconditional.  A lane whose channel does not
-            // exist (channel tail of the last k-step, k-steps past the end of a short last chunk)
-            // re-reads an existing channel and the value is replaced by an exact 0; its A operand
-            // is a staged 0 as well, so the accumulator is unchanged bit for bit.
-            const int k0 = ch * (ACH / 4);
-#define D2T_TSTEP(Q, KK)                                                                        \
-            {                                                                                   \
-                const f32x4 q_ = (4 * (k0 + (KK)) + g < C) ? (Q) : f32x4{0.f, 0.f, 0.f, 0.f};   \
-                const float a_ = cur[((KK) * 4 + g) * 16 + n];                                  \
-                acc0 = D2T_MFMA(a_, q_.x, acc0);                                                \
-                acc1 = D2T_MFMA(a_, q_.y, acc1);                                                \
-                acc2 = D2T_MFMA(a_, q_.z, acc2);                                                \
-                acc3 = D2T_MFMA(a_, q_.w, acc3);                                                \
-            }
-#pragma unroll 2
-            for (int kk = 0; kk < ACH / 4; kk += 4) {                // loads run 4 k-steps ahead
-                const f32x4 q0 = qa; qa = t_load(k0 + kk + 4); D2T_TSTEP(q0, kk);
-                const f32x4 q1 = qb; qb = t_load(k0 + kk + 5); D2T_TSTEP(q1, kk + 1);
-                const f32x4 q2 = qc; qc = t_load(k0 + kk + 6); D2T_TSTEP(q2, kk + 2);
-                const f32x4 q3 = qd; qd = t_load(k0 + kk + 7); D2T_TSTEP(q3, kk + 3);
-            }
-#undef D2T_TSTEP
-        }
-        a_put(smem + ((ch + 1) & 1) * ACH * 16, anext, ch + 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: out tile [16 pixels][17][17] through LDS ----
-    __syncthreads();
-    for (int e = tid; e < 16 * CELLS; e += FWD_THREADS) smem[e] = 0.f;
-    __syncthreads();
-    if (active && gsel < NG) {
-        // lane holds D[m = 4g + r][column n of N-tile t]: pixel (i0+g, j0+r), displaced (di, djs+t)
-        const int ci = wr - g;                          // di - i + d
-        if (ci >= 0 && ci < 2 * DT) {
-            float* row = smem + (4 * g) * CELLS + ci * CW;
-            const f32x4 a4[4] = {acc0, acc1, acc2, acc3};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cj = djs + t - (j0 + r) + DT;
-                    if (cj >= 0 && cj < 2 * DT) row[r * CELLS + cj] = a4[t][r];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int nj = W - j0 < TP ? W - j0 : TP;
-    for (int pi = 0; pi < TP; ++pi) {
-        const int i = i0 + pi;
-        if (i >= H) break;
-        float* dst = out + (((size_t)b * H + i) * W + j0) * CELLS;
-        const float* src = smem + pi * 4 * CELLS;
-        for (int e = tid; e < nj * CELLS; e += FWD_THREADS) dst[e] = src[e];
-    }
-}
-
 // ------------------------------------------------------------------------------------
 // Forward, LDS-staged segment kernel (the default when the grid fills the chip).
-// The tile kernel above gathers every p-tile's 19 x 20 window straight from L2 in 80-byte row
-// pieces; rocprofv3 shows its texture-address unit 85 % busy (TA_TA_BUSY) at ~25 useful bytes per
+// A tile-per-workgroup kernel gathers every p-tile's 19 x 20 window straight from L2 in 80-byte row
+// pieces; rocprofv3 showed its texture-address unit 85 % busy (TA_TA_BUSY) at ~25 useful bytes per
 // 64-byte sector, i.e. it is bound by the gather, not by MFMA or HBM.  Here one workgroup owns a
 // segment of 5 vertically stacked p-tiles: the union of their windows (<= 35 rows x 20 columns) is
 // copied ONCE per 16 channels into LDS (2.7x fewer bytes through the TA), and every wave reads its
@@ -406,11 +273,233 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Forward, small grids (the real model's B = 1 pairs: 160-190 p-tiles in all).  Same LDS-staged
+// scheme as k_corr_fwd_seg with short segments (NU = 1 or 2 p-tiles, 3*NU waves) so that every CU
+// gets a workgroup.  With so few waves per CU nothing hides the DMA latency of a chunk behind the
+// MFMAs of a single other chunk, so the chunks go through a RING of staged buffers: chunk ch is
+// consumed while ch+1 .. ch+RING-1 are in flight.  LDS-DMA loads retire in order and every wave
+// issues exactly NDMA of them per chunk (surplus ones are parked out of range and land as zeros in
+// a dummy slot), so "vmcnt <= (RING-2)*NDMA" means this wave's part of chunk ch+1 has landed; the
+// barrier then publishes all parts.  (__syncthreads() would wait for vmcnt(0) and serialise the
+// latency.)  Arithmetic unchanged: bit-identical to the other forward kernels.
+// ------------------------------------------------------------------------------------
+template <int NU, int RING>
+struct SegX {
+    static constexpr int WAVES = 3 * NU;                             // 6*NU (tile, tile-group) tasks, two per wave
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int ROWS = 4 * NU + 2 * DT - 1;                 // window rows of a segment
+    static constexpr int SLOTS = (ROWS * NCG + 15) / 16 * 16;        // 16-byte slots per channel: plane stride = 0 mod 64 dwords
+    static constexpr int BPL = SLOTS * 4;
+    static constexpr int APL = NU * 16;
+    static constexpr int BUF = SG_KC * (BPL + APL);                  // floats per staged chunk
+    static constexpr int STAGE = NU * 16 * CELLS;                    // out staging, aliases the ring
+    static constexpr int DUMMY = 256;                                // floats: where parked DMA instructions land
+    static constexpr int LDS = RING * BUF + DUMMY > STAGE ? RING * BUF + DUMMY : STAGE;
+    static constexpr int BI = SG_KC * SLOTS / 64;                    // FM1 DMA wave-instructions per chunk
+    static constexpr int AI = SG_KC * 4 * NU / 64;                   // FM0 ones
+    static constexpr int KB = (BI + WAVES - 1) / WAVES;              // FM1 / FM0 DMA instructions per wave per chunk:
+    static constexpr int KA = (AI + WAVES - 1) / WAVES;              // the same count (and kind, per position) for every wave
+    static constexpr int NDMA = KB + KA;
+    static constexpr int INFLIGHT = (RING - 3) * NDMA;               // DMA instructions that may still be outstanding at a barrier
+    static_assert(INFLIGHT <= 63, "vmcnt is a 6-bit counter");
+    static_assert(LDS * 4 <= 160 * 1024, "LDS budget");
+};
+
+template <int N>
+__device__ __forceinline__ void dma_wait_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int NU, int RING>
+__global__ void __launch_bounds__(3 * NU * 64)
+k_corr_fwd_segx(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
+                int C, int H, int W, int tiles_i, int tiles_j, int nseg)
+{
+    using S = SegX<NU, RING>;
+    __shared__ __attribute__((aligned(16))) float smem[S::LDS];
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
+    const int u0 = seg * NU, nu = tiles_i - u0 < NU ? tiles_i - u0 : NU;
+    const int j0 = tj * TP, HW = H * W;
+    const unsigned plane_bytes = (unsigned)C * HW * 4u;
+    const __amdgpu_buffer_rsrc_t r1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm1 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm0 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * HW * CELLS, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
+
+    const int R0 = 4 * u0 - DT > 0 ? 4 * u0 - DT : 0;                // region rows [R0, R1) inside the map
+    const int R1 = 4 * (u0 + nu) + DT - 1 < H ? 4 * (u0 + nu) + DT - 1 : H;
+    const int nrows = R1 - R0;
+    const int colL = j0 - DT;                                        // region columns [colL, colL+20): may leave the map
+
+    // ---- DMA plan: a wave-instruction moves 64 pieces of 16 bytes.  Position k < KB of a wave's
+    // sequence is FM1 instruction x = wave + WAVES*k (slots 64x .. 64x+63 of the [channel][row]
+    // [column group] image), position KB + k is FM0 instruction x = wave + WAVES*k (pieces (channel,
+    // pixel row of the segment)); an x past the end is parked: out of range -> zeros into the dummy
+    // slot.  The kind of every position is static, so staging is branch-free.
+    constexpr int OOR = 0x7ffffff0;
+    int dv[S::NDMA], dl[S::NDMA];                                    // byte offset in the planes / float offset in the buffer
+#pragma unroll
+    for (int k = 0; k < S::KB; ++k) {
+        const int x = wave + S::WAVES * k;
+        const int e = x * 64 + lane;
+        const int ch = e / S::SLOTS, rem = e - ch * S::SLOTS;
+        const int row = rem / NCG, cg = rem - row * NCG;             // pad slots have row >= ROWS >= nrows
+        dv[k] = x < S::BI && row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 : OOR;
+        dl[k] = x < S::BI ? x * 256 : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < S::KA; ++k) {
+        const int x = wave + S::WAVES * k;
+        const int e = x * 64 + lane;
+        const int ch = e / (4 * NU), prow = e - ch * (4 * NU);
+        const int i = 4 * u0 + prow;
+        dv[S::KB + k] = x < S::AI && i < H ? (ch * HW + i * W + j0) * 4 : OOR;
+        dl[S::KB + k] = x < S::AI ? SG_KC * S::BPL + x * 256 : -1;
+    }
+    const int chunk_bytes = SG_KC * HW * 4;
+    auto stage = [&](float* buf, int chunk) {
+        const int cb = chunk * chunk_bytes;
+#pragma unroll
+        for (int k = 0; k < S::NDMA; ++k) {
+            const int v = dv[k] == OOR ? OOR : dv[k] + cb;
+            float* dst = dl[k] >= 0 ? buf + dl[k] : smem + RING * S::BUF;
+            if (k < S::KB) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, v, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)dst, 16, v, 0, 0, 0);
+        }
+    };
+
+    // ---- this wave's two tasks: id = tile*6 + tile-group
+    int t_tile[2], t_off[2], t_ng[2];
+    bool t_on[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int id = wave + S::WAVES * k, t = id / 6, T = id - t * 6;
+        const int u = u0 + t;
+        const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;              // tile's window rows inside the map
+        const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
+        const int ng = (wb - wa) * NCG;
+        t_tile[k] = t;
+        t_ng[k] = ng;
+        t_on[k] = t < nu && 16 * T < ng;
+        t_off[k] = ((wa - R0) * NCG + 16 * T) * 4;                   // float offset of the tile-group's first slot
+    }
+    int l_off[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int T = (wave + S::WAVES * k) % 6;
+        int gi = 16 * T + n;
+        gi = gi < t_ng[k] ? gi : (t_ng[k] > 0 ? t_ng[k] - 1 : 0);
+        l_off[k] = t_on[k] ? t_off[k] - 16 * T * 4 + gi * 4 + g * S::BPL : g * S::BPL;
+    }
+    const int a_off0 = SG_KC * S::BPL + g * S::APL + (t_on[0] ? t_tile[0] : 0) * 16 + n;
+    const int a_off1 = SG_KC * S::BPL + g * S::APL + (t_on[1] ? t_tile[1] : 0) * 16 + n;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[k][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (C + SG_KC - 1) / SG_KC;
+    // MFMA fragments of a chunk (both tasks; a missing task reads a valid slot into a dead
+    // accumulator, so the loop body is straight-line)
+    struct Frag { f32x4 q0[SG_KC / 4], q1[SG_KC / 4]; float a0[SG_KC / 4], a1[SG_KC / 4]; };
+    auto fetch = [&](Frag& f, const float* cur) {
+#pragma unroll
+        for (int ks = 0; ks < SG_KC / 4; ++ks) {
+            f.q0[ks] = *reinterpret_cast<const f32x4*>(cur + l_off[0] + ks * 4 * S::BPL);
+            f.q1[ks] = *reinterpret_cast<const f32x4*>(cur + l_off[1] + ks * 4 * S::BPL);
+            f.a0[ks] = cur[a_off0 + ks * 4 * S::APL];
+            f.a1[ks] = cur[a_off1 + ks * 4 * S::APL];
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < RING - 1; ++p) stage(smem + p * S::BUF, p);  // past the end of C: zeros
+    dma_wait_barrier<S::INFLIGHT>();                                 // chunks 0 and 1 have landed
+    Frag cur_f, nxt_f;
+    fetch(cur_f, smem);
+    int slot = 0;                                                    // ring slot of chunk ch
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int free_slot = slot == 0 ? RING - 1 : slot - 1;       // chunk ch-1: in registers since iteration ch-2
+        const int next_slot = slot + 1 == RING ? 0 : slot + 1;       // chunk ch+1: published by the last barrier
+        stage(smem + free_slot * S::BUF, ch + RING - 1);
+        fetch(nxt_f, smem + next_slot * S::BUF);                     // lands under this chunk's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < SG_KC / 4; ++ks) {
+            acc[0][0] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].x, acc[0][0]);
+            acc[1][0] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].x, acc[1][0]);
+            acc[0][1] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].y, acc[0][1]);
+            acc[1][1] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].y, acc[1][1]);
+            acc[0][2] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].z, acc[0][2]);
+            acc[1][2] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].z, acc[1][2]);
+            acc[0][3] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].w, acc[0][3]);
+            acc[1][3] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].w, acc[1][3]);
+        }
+        dma_wait_barrier<S::INFLIGHT>();                             // chunk ch+2 has landed; chunk ch+1 is in registers
+        cur_f = nxt_f;
+        slot = next_slot;
+    }
+    __syncthreads();                                                 // vmcnt(0): the zero chunks staged past the end
+
+    // ---- epilogue: [nu tiles][16 pixels][17][17] through LDS, then 4*nu contiguous runs ----
+    for (int e = tid; e < nu * 16 * CELLS; e += S::THREADS) smem[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int T = (wave + S::WAVES * k) % 6;
+        const int gi = 16 * T + n;
+        if (t_on[k] && gi < t_ng[k]) {
+            const int u = u0 + t_tile[k];
+            const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;
+            const int rho = wa + gi / NCG, cg = gi - (gi / NCG) * NCG;   // displaced row, column group
+            const int ci = rho - (4 * u + g) + DT;                   // di - i + d, pixel row i = 4u + g
+            if (ci >= 0 && ci < 2 * DT) {
+                float* row = smem + (t_tile[k] * 16 + 4 * g) * CELLS + ci * CW;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int dj = colL + 4 * cg + s;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cj = dj - (j0 + r) + DT;
+                        if (cj >= 0 && cj < 2 * DT && dj >= 0 && dj < W) row[r * CELLS + cj] = acc[k][s][r];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nj = W - j0 < TP ? W - j0 : TP;
+    const int run = nj * CELLS, run4 = run >> 2;                     // floats / whole float4s per pixel row
+    const int prs = (H - 4 * u0 < 4 * nu ? H - 4 * u0 : 4 * nu);     // pixel rows that exist
+    for (int e = tid; e < prs * run4; e += S::THREADS) {
+        const int pr = e / run4, q = e - pr * run4;
+        const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
+                                               ro, off, 0, 16);     // aux 16 = sc1 (write-through)
+    }
+    const int tail = run - 4 * run4;                                 // 0..3 floats per pixel row (nj < 4)
+    for (int e = tid; e < prs * tail; e += S::THREADS) {
+        const int pr = e / tail, q = 4 * run4 + (e - pr * tail);
+        out[((size_t)b * HW + (4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
+    }
+}
+
 bool corr_fwd_supported(int B, int C, int H, int W, int d, int s)
 {
     if (d != DT || s != 1 || B < 1 || C < 1 || H < 1 || W < WC) return false;
     const long long blocks = 1LL * B * ((H + TP - 1) / TP) * ((W + TP - 1) / TP);
-    return blocks <= 0x7fffffffLL;
+    // 32-bit byte offsets inside one batch item (feature planes incl. the chunks staged past C; output)
+    const bool offsets_fit = (C + 8LL * SG_KC) * H * W * 4 < 0x7ffffff0LL && 1LL * H * W * CELLS * 4 < 0x7ffffff0LL;
+    return blocks <= 0x7fffffffLL && offsets_fit;
 }
 
 size_t corr_fwd_ws_bytes(int, int, int, int, int, int) { return 0; }
@@ -424,10 +513,13 @@ int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, i
     if (strip_blocks >= 192) {                       // enough segments to give (nearly) every CU one
         hipLaunchKernelGGL(k_corr_fwd_seg, dim3((int)strip_blocks), dim3(SG_THREADS), 0, st,
                            fm0, fm1, out, C, H, W, tiles_i, tiles_j, nseg);
-    } else {                                         // small batches: one p-tile per workgroup
-        const int blocks = B * tiles_i * tiles_j;
-        hipLaunchKernelGGL(k_corr_fwd_mfma, dim3(blocks), dim3(FWD_THREADS), 0, st,
-                           fm0, fm1, out, C, H, W, tiles_i, tiles_j);
+    } else if (1LL * B * tiles_j * ((tiles_i + 1) / 2) >= 160) {    // medium: segments of 2 p-tiles
+        const int ns = (tiles_i + 1) / 2;
+        hipLaunchKernelGGL((k_corr_fwd_segx<2, 4>), dim3(B * tiles_j * ns), dim3(SegX<2, 4>::THREADS), 0, st,
+                           fm0, fm1, out, C, H, W, tiles_i, tiles_j, ns);
+    } else {                                         // small batches (B = 1 pairs): one p-tile per workgroup
+        hipLaunchKernelGGL((k_corr_fwd_segx<1, 4>), dim3(B * tiles_j * tiles_i), dim3(SegX<1, 4>::THREADS), 0, st,
+                           fm0, fm1, out, C, H, W, tiles_i, tiles_j, tiles_i);
     }
     return launch_status();
 }

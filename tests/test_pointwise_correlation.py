@@ -70,6 +70,8 @@ CASES = [  # (B, C, H, W, d, s)
     (2, 5, 7, 9, 1, 1), (1, 3, 4, 5, 0, 1), (1, 8, 5, 3, 4, 1), (1, 7, 9, 9, 2, 5),
     (2, 64, 19, 23, 8, 1), (1, 256, 38, 63, 8, 1), (1, 96, 38, 75, 8, 1), (3, 33, 17, 31, 8, 1),
     (1, 4, 40, 70, 8, 1), (2, 128, 8, 8, 8, 1),
+    # one case per tuned forward kernel: 2-tile segments, 5-tile segments off the headline shape, 1-tile
+    (2, 48, 38, 63, 8, 1), (3, 20, 38, 75, 8, 1), (1, 70, 38, 75, 8, 1),
 ]
 
 
