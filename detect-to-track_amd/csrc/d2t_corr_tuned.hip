@@ -26,6 +26,7 @@
 // The first generation (one p-tile per workgroup, FM1 gathered straight from L2) measured
 // texture-address-bound and is gone; DESIGN.md section 4.2 keeps its numbers.
 #include "d2t_tuned.hpp"
+#include <type_traits>
 
 namespace d2t { namespace tuned {
 
@@ -669,9 +670,13 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
     f32x4 av = s_load(0, 0);
     __syncthreads();
 
-    // The loop body is straight-line code (no branches): every load is unconditional, so the
+    // The super-step body is straight-line code (no branches): every load is unconditional, so the
     // compiler can retire them with counted s_waitcnt instead of draining at block boundaries.
-    for (int ss = 0; ss < tiles_i; ++ss) {
+    // LO/HI: the live accumulators [LO, HI) of this super-step -- the first two super-steps carry
+    // tiles -2/-1 in acc[0..1], the last two carry tiles past the map in acc[3..4]; their MFMAs
+    // (12 % of the strip at 38 rows) are never stored and are not issued.
+    auto super_step = [&](int ss, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         const int cur = ss & 1;
         const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
 #pragma unroll
@@ -680,11 +685,11 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
             av = q + 1 < KB_SS ? s_load(ss, q + 1) : s_load(ss + 1, 0);
             f32x4 bv[NACT];
 #pragma unroll
-            for (int a = 0; a < NACT; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
+            for (int a = LO; a < HI; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {                            // s outer: 5 independent accumulators
+            for (int s = 0; s < 4; ++s) {                            // s outer: independent accumulators
 #pragma unroll
-                for (int a = 0; a < NACT; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
+                for (int a = LO; a < HI; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
             }
         }
         // hand super-step ss+1's G (requested a whole super-step ago) to the other buffer, then
@@ -699,6 +704,16 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
 #pragma unroll
         for (int a = 0; a + 1 < NACT; ++a) acc[a] = acc[a + 1];
         acc[NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    using std::integral_constant;
+    if (tiles_i >= 4) {
+        super_step(0, integral_constant<int, 2>{}, integral_constant<int, NACT>{});
+        super_step(1, integral_constant<int, 1>{}, integral_constant<int, NACT>{});
+        for (int ss = 2; ss < tiles_i - 2; ++ss) super_step(ss, integral_constant<int, 0>{}, integral_constant<int, NACT>{});
+        super_step(tiles_i - 2, integral_constant<int, 0>{}, integral_constant<int, NACT - 1>{});
+        super_step(tiles_i - 1, integral_constant<int, 0>{}, integral_constant<int, NACT - 2>{});
+    } else {
+        for (int ss = 0; ss < tiles_i; ++ss) super_step(ss, integral_constant<int, 0>{}, integral_constant<int, NACT>{});
     }
     store_tile(acc[0], tiles_i - 2);                                 // their remaining super-steps lie below the map
     store_tile(acc[1], tiles_i - 1);
