@@ -17,12 +17,12 @@
 //    read-add-write, one channel per lane); the partial rows are added in a fixed order.
 //  * PSROIPool backward, phase 1: a workgroup owns one OUTPUT plane (t, bin) -- every plane has
 //    exactly R cells, so the grid is balanced whatever the many-to-one channel map
-//    ((t+1)*bin, ps_roipool_cuda.cu:58) does.  Its 4 waves own bands of map rows, a lane owns the
-//    pixels of its column(s) in the band, accumulators live in REGISTERS.  64 RoIs are fetched
-//    and tested per instruction (lane = RoI, ballot), the hits are then visited in ascending
-//    order out of registers (v_readlane).  Phase 2 adds, per input channel, the planes that map
-//    to it in ascending (bin, t) order.
-//  No atomics of any kind (global or LDS), no accumulator shared between waves, every gradIn
+//    ((t+1)*bin, ps_roipool_cuda.cu:58) does.  Its 4 waves own a quarter of the RoIs each and a
+//    private copy of the plane in LDS (k_psroipool_bwd_plane_lds; maps above 4096 pixels: bands of
+//    rows in registers, k_psroipool_bwd_plane).  64 RoIs are fetched per instruction (lane = RoI).
+//    Phase 2 adds, per input channel, the planes that map to it in ascending (bin, t) order.
+//  No accumulator is shared between waves (the one ds_add_f32 use is on a wave-private plane:
+//  in-order, no contention), every gradIn
 //  element written once, fixed summation order: bitwise reproducible.
 #include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
@@ -355,49 +355,114 @@ k_psroipool_bwd_plane(const float* __restrict__ gout, const int32_t* __restrict_
     }
 }
 
-// The planes that map to an input channel: (t+1)*bin == ch, i.e. bin | ch with ch/bin <= nT
-// (ps_roipool_cuda.cu:58); channel 0 collects bin 0 of every t.  One small kernel inverts the map
-// once per call: src[ch][0..PS_MAXSRC) = plane indices in ascending (bin, t) order, -1 terminated.
-constexpr int PS_MAXSRC = 48;                       // >= max(nT for ch 0 capped, divisors <= 48 of ch)
+// ---------------------------------------------------------------------------------------
+// PSROIPool backward, phase 1, LDS form (maps up to 4096 pixels).  Workgroup = output plane
+// (t, bin); each of the 4 waves owns a quarter of the RoIs and a PRIVATE copy of the plane in LDS.
+// 64 RoIs are fetched per instruction (lane = RoI) and their cells computed on the fly (no cell
+// table, no extra launch).  Two ways to add them, chosen by the launcher:
+//   SWEEP = false  every non-empty cell in turn (ascending r) by the lanes of an 8 x 8 grid laid
+//                  over it: one LDS read-add-write of <= 64 pixels, ~25 instructions per cell (the
+//                  register-band form above needs ~80: it tests all of its rows against every cell);
+//   SWEEP = true   all 64 cells together, pixel (dy, dx) of every cell per step, with ds_add_f32
+//                  on the wave-private plane: ~5 instructions per cell but ~3.4 cycles per lane in
+//                  the LDS -- wins when there are too few planes to hide the per-cell latency.
+// Each wave adds its RoIs in ascending order, the four copies are summed in wave order.
+// ---------------------------------------------------------------------------------------
+constexpr int PL_WAVES = 4;
+constexpr int PL_MAXPIX = 4096;                                      // 4 planes x 16 KB = 64 KB of LDS
 
-__global__ void __launch_bounds__(64)
-k_psroipool_invert_map(int32_t* __restrict__ src, int nT)
+template <bool SWEEP>
+__global__ void __launch_bounds__(PL_WAVES * 64)
+k_psroipool_bwd_plane_lds(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ part,
+                          int R, int nT, int H, int W)
 {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= nT * KK) return;
-    int32_t* d = src + (size_t)ch * PS_MAXSRC;
-    int m = 0;
-    if (ch == 0) {
-        // bin 0 of every target maps to channel 0; nT may exceed the table: phase 2 handles ch 0 itself
-        d[0] = -1;
-        return;
+    extern __shared__ float planes[];                                // [PL_WAVES][H*W]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int plane = blockIdx.x, bin = plane % KK, HW = H * W;      // plane = t*49 + bin
+    float* mine = planes + wave * HW;
+    for (int e = lane; e < HW; e += 64) mine[e] = 0.f;
+    const int dy = lane >> 3, dx = lane & 7, loff = dy * W + dx;
+    const int r_lo = (int)((long long)R * wave / PL_WAVES), r_hi = (int)((long long)R * (wave + 1) / PL_WAVES);
+    const int bi = bin / KT, bj = bin - bi * KT;
+    const float* gp = gout + plane;
+    for (int rb = r_lo; rb < r_hi; rb += 64) {
+        const int rr = rb + lane;
+        int4 cb = make_int4(0, 0, 0, 0);                             // (i0, i1, j0, j1) of this RoI's cell
+        float v = 0.f;
+        if (rr < r_hi) {
+            const Bounds c = psroi_cell<float>(rois + 4 * (size_t)rr, bi, bj, H, W, KT);
+            cb = make_int4(c.i0, c.i1, c.j0, c.j1);
+            v = gp[(size_t)rr * nT * KK];
+        }
+        const int n = (cb.y - cb.x) * (cb.w - cb.z);
+        const bool hit = cb.y > cb.x && cb.w > cb.z;
+        v = v / static_cast<float>(n > 0 ? n : 1);                   // ps_roipool_cuda.cu:135
+        if (SWEEP) {
+            // lane = RoI: the 64 cells are swept together, pixel (dy, dx) of every cell per step, with
+            // LDS float adds (the plane is private to the wave: no contention, fixed order)
+            const int h = hit ? cb.y - cb.x : 0, w = cb.w - cb.z;
+            float* p = mine + cb.x * W + cb.z;
+            for (int sy = 0; __ballot(sy < h); ++sy)
+                for (int sx = 0; __ballot(sy < h && sx < w); ++sx)
+                    if (sy < h && sx < w)
+                        __hip_atomic_fetch_add(p + sy * W + sx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            continue;
+        }
+        // cells are visited one at a time in ascending r; the lanes form an 8 x 8 grid laid over the
+        // cell: one LDS read-add-write covers it (larger cells take more grid positions)
+        const int base = cb.x * W + cb.z;
+        const int hw = ((cb.y - cb.x) << 16) | (cb.w - cb.z);
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int sb = __builtin_amdgcn_readlane(base, l), shw = __builtin_amdgcn_readlane(hw, l);
+            const float vv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+            const int h = shw >> 16, w = shw & 0xffff;
+            float* p = mine + sb + loff;
+            if (h <= 8 && w <= 8) {                                  // wave-uniform: the usual case
+                if (dy < h && dx < w) *p += vv;
+            } else {
+                for (int ty = 0; ty < h; ty += 8)
+                    for (int tx = 0; tx < w; tx += 8)
+                        if (ty + dy < h && tx + dx < w) p[ty * W + tx] += vv;
+            }
+        }
     }
-    for (int bin = 1; bin < KK; ++bin) {
-        if (ch % bin != 0) continue;
-        const int tp1 = ch / bin;
-        if (tp1 <= nT && m < PS_MAXSRC - 1) d[m++] = (tp1 - 1) * KK + bin;
-    }
-    d[m] = -1;
+    __syncthreads();
+    float* dst = part + (size_t)plane * HW;
+    for (int e = threadIdx.x; e < HW; e += PL_WAVES * 64)
+        dst[e] = ((planes[e] + planes[HW + e]) + planes[2 * HW + e]) + planes[3 * HW + e];
 }
+
+// Phase 2: the planes that map to an input channel are (t, bin) with (t+1)*bin == ch, i.e. bin | ch
+// with ch/bin <= nT (ps_roipool_cuda.cu:58); channel 0 collects bin 0 of every t.  Each workgroup
+// finds its channel's planes itself (ascending bin) and adds them in that fixed order.
 
 // phase 2: gin[ch] = sum of the planes that map to ch, ascending bin then t; channels nothing
 // maps to are zero.
 __global__ void __launch_bounds__(256)
-k_psroipool_bwd_gather(const float* __restrict__ part, const int32_t* __restrict__ src, float* __restrict__ gin,
-                       int nT, int HW)
+k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, int nT, int HW)
 {
+    // planes (t, bin) with (t+1)*bin == ch, ascending bin: lane b-1 of the first wave tests bin b
+    __shared__ int32_t srcs[KK];
+    __shared__ int nsrc;
     const int ch = blockIdx.y;
-    const int32_t* sl = src + (size_t)ch * PS_MAXSRC;                // wave-uniform
+    if (threadIdx.x < 64) {
+        const int bin = threadIdx.x + 1;
+        const bool is_src = ch > 0 && bin < KK && ch % bin == 0 && ch / bin <= nT;
+        const unsigned long long m = __ballot(is_src);
+        if (is_src) srcs[__builtin_popcountll(m & ((1ull << threadIdx.x) - 1ull))] = (ch / bin - 1) * KK + bin;
+        if (threadIdx.x == 0) nsrc = __builtin_popcountll(m);
+    }
+    __syncthreads();
+    const int ns = nsrc;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
         float a = 0.f;
-        if (ch == 0) {
+        if (ch == 0) {                                               // bin 0 of every target
             for (int t = 0; t < nT; ++t) a += part[(size_t)(t * KK) * HW + p];
         } else {
-            for (int k = 0; k < PS_MAXSRC; ++k) {
-                const int pl = sl[k];
-                if (pl < 0) break;
-                a += part[(size_t)pl * HW + p];
-            }
+            for (int k = 0; k < ns; ++k) a += part[(size_t)srcs[k] * HW + p];
         }
         gin[(size_t)ch * HW + p] = a;
     }
@@ -411,30 +476,36 @@ bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
 size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
 {
     if (!psroipool_bwd_supported(R, nT, H, W, k)) return 0;
-    return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float)) +
-           align256((size_t)nT * KK * PS_MAXSRC * sizeof(int32_t));
+    return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float));
 }
 
 int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
                       void* ws, hipStream_t st)
 {
-    int32_t* cells = static_cast<int32_t*>(ws);
+    int32_t* cells = static_cast<int32_t*>(ws);                      // only the register-band form reads a cell table
     float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + bins_bytes(R));
-    int32_t* src = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + bins_bytes(R) +
-                                              align256((size_t)nT * KK * H * W * sizeof(float)));
-    int rc = psroipool_bins<float>(rois, cells, R, H, W, k, st);
-    if (rc != D2T_OK) return rc;
-    hipLaunchKernelGGL(k_psroipool_invert_map, dim3((nT * KK + 63) / 64), dim3(64), 0, st, src, nT);
-    rc = launch_status();
-    if (rc != D2T_OK) return rc;
-    if (H <= 40)
-        hipLaunchKernelGGL(k_psroipool_bwd_plane<10>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
-    else
-        hipLaunchKernelGGL(k_psroipool_bwd_plane<PX_MAXROWS>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
+    int rc;
+    if (H * W <= PL_MAXPIX) {
+        // few planes (< 2 workgroups per CU): one wave per SIMD, latency-bound -> sweep 64 cells at a time;
+        // many planes: the LDS float-add rate (~3.4 cycles per lane) would bound -> per-cell read-add-write
+        if (nT * KK < 512)
+            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<true>, dim3(nT * KK), dim3(PL_WAVES * 64),
+                               (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
+        else
+            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<false>, dim3(nT * KK), dim3(PL_WAVES * 64),
+                               (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
+    } else {
+        rc = psroipool_bins<float>(rois, cells, R, H, W, k, st);
+        if (rc != D2T_OK) return rc;
+        if (H <= 40)
+            hipLaunchKernelGGL(k_psroipool_bwd_plane<10>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
+        else
+            hipLaunchKernelGGL(k_psroipool_bwd_plane<PX_MAXROWS>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
+    }
     rc = launch_status();
     if (rc != D2T_OK) return rc;
     const int HW = H * W;
-    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, src, gin, nT, HW);
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
     return launch_status();
 }
 
