@@ -26,6 +26,7 @@
 //  element written once, fixed summation order: bitwise reproducible.
 #include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
+#include <type_traits>
 
 namespace d2t { namespace tuned {
 
@@ -75,22 +76,43 @@ constexpr int GEO = 32;
 inline size_t geo_bytes(int R) { return align256((size_t)R * GEO * sizeof(int32_t)); }
 
 __global__ void __launch_bounds__(64)
-k_roi_geom(const float* __restrict__ rois, int32_t* __restrict__ geo, int R, int H, int W)
+k_roi_geom(const float* __restrict__ rois, int32_t* __restrict__ geo, uint8_t* __restrict__ rowmask,
+           float* __restrict__ rcp, int R, int H, int W)
 {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= R) return;
+    // one wave per RoI: lane i < 7 evaluates bin row i / bin column i, the tables are filled in parallel
+    const int r = blockIdx.x, lane = threadIdx.x;
     int32_t* g = geo + (size_t)r * GEO;
+    Bounds b{0, 0, 0, 0};
+    if (lane < KT) b = roi_bin<float>(rois + 4 * r, lane, lane, H, W, KT);   // (i, i): row bounds of i, column bounds of j = i
+    int i0[KT], i1[KT], j0[KT], j1[KT];
 #pragma unroll
-    for (int i = 0; i < KT; ++i) {
-        const Bounds b = roi_bin<float>(rois + 4 * r, i, i, H, W, KT);     // (i, i): row bounds of i, column bounds of j = i
-        g[i] = b.i0; g[KT + i] = b.i1; g[2 * KT + i] = b.j0; g[3 * KT + i] = b.j1;
+    for (int q = 0; q < KT; ++q) {
+        i0[q] = __builtin_amdgcn_readlane(b.i0, q); i1[q] = __builtin_amdgcn_readlane(b.i1, q);
+        j0[q] = __builtin_amdgcn_readlane(b.j0, q); j1[q] = __builtin_amdgcn_readlane(b.j1, q);
     }
-    g[28] = g[0]; g[29] = g[2 * KT - 1]; g[30] = g[2 * KT]; g[31] = g[4 * KT - 1];
+    if (lane < KT) { g[lane] = b.i0; g[KT + lane] = b.i1; g[2 * KT + lane] = b.j0; g[3 * KT + lane] = b.j1; }
+    if (lane == 0) { g[28] = i0[0]; g[29] = i1[KT - 1]; g[30] = j0[0]; g[31] = j1[KT - 1]; }
+    if (rowmask) {                                                   // bit i of rowmask[r][y]: bin row i contains map row y
+        for (int y = lane; y < H; y += 64) {
+            int mk = 0;
+#pragma unroll
+            for (int i = 0; i < KT; ++i) mk |= (y >= i0[i] && y < i1[i]) ? 1 << i : 0;
+            rowmask[(size_t)r * H + y] = (uint8_t)mk;
+        }
+    }
+    if (rcp && lane < KK) {                                          // 1 / binNumel of the 49 bins (0 for empty bins)
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < KT; ++i)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) n = lane == i * KT + j ? (i1[i] - i0[i]) * (j1[j] - j0[j]) : n;
+        rcp[(size_t)r * 64 + lane] = n > 0 ? 1.0f / static_cast<float>(n) : 0.f;
+    }
 }
 
-static int roi_geom(const float* rois, int32_t* geo, int R, int H, int W, hipStream_t st)
+static int roi_geom(const float* rois, int32_t* geo, uint8_t* rowmask, float* rcp, int R, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_roi_geom, dim3((R + 63) / 64), dim3(64), 0, st, rois, geo, R, H, W);
+    hipLaunchKernelGGL(k_roi_geom, dim3(R), dim3(64), 0, st, rois, geo, rowmask, rcp, R, H, W);
     return launch_status();
 }
 
@@ -177,7 +199,7 @@ int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C
     int32_t* geo = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + align256((size_t)C * H * W * sizeof(float)));
     int rc = transpose(fm, fmt, C, H * W, st);                       // (C, HW) -> (HW, C)
     if (rc != D2T_OK) return rc;
-    rc = roi_geom(rois, geo, R, H, W, st);
+    rc = roi_geom(rois, geo, nullptr, nullptr, R, H, W, st);
     if (rc != D2T_OK) return rc;
     hipLaunchKernelGGL(k_roipool_fwd_cl, dim3(R, (C + 63) / 64), dim3(RF_THREADS), 0, st, fmt, geo, out, C, W);
     return launch_status();
@@ -255,16 +277,156 @@ k_transpose_gout(const float* __restrict__ in, float* __restrict__ out, int C)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// ROIPool backward, batched channel-last form (the default).  Decomposition as k_roipool_bwd_cl:
+// workgroup = (map row y, 64 channels), one channel per lane, each wave a share of the RoIs and a
+// private LDS accumulator [W+1][65] (row W is a dummy).  What differs is everything that made
+// that kernel a chain of latencies:
+//  * work items (RoI r, bin row i containing y) come out of a row-mask table, 64 RoIs per
+//    instruction (lane = RoI): no scalar load per RoI;
+//  * RC_PF items are in flight: geometry record, 7 reciprocals and the 7 x 256 bytes of
+//    (transposed) gradOut are fetched RC_PF items ahead of their use;
+//  * 1/binNumel comes from a table written by k_roi_geom (one multiply instead of a divide per
+//    bin: <= 1 ulp from gradOut/n, the reference's atomics leave the order undefined anyway);
+//  * the pixels of the even column bins (disjoint when the RoI is >= 7 pixels wide) are read
+//    together, added, written together, then the odd bins: 2 LDS round trips per item instead of
+//    one per pixel (27 on average).  Slots past a bin's width go to the dummy row.
+// Per pixel the order is ascending (r, i, j) within a wave; the waves' rows are added in order.
+// ---------------------------------------------------------------------------------------
+constexpr int RC_PF = 4;                                             // work items in flight per wave
+
+__global__ void __launch_bounds__(256)
+k_roipool_bwd_batched(const float* __restrict__ gt, const int32_t* __restrict__ geo, const uint8_t* __restrict__ rowmask,
+                      const float* __restrict__ rcp, float* __restrict__ gin, int R, int C, int H, int W)
+{
+    extern __shared__ float lds[];                                   // [waves][W+1][65]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int y = blockIdx.x, c0 = blockIdx.y * 64;
+    const int per = (W + 1) * RB_LD;
+    float* acc = lds + (size_t)wave * per + lane;
+    for (int x = 0; x <= W; ++x) acc[x * RB_LD] = 0.f;
+    const int cl = c0 + lane < C ? c0 + lane : C - 1;                // clamped lane channel (never stored)
+    const int r_lo = (int)((long long)R * wave / nw), r_hi = (int)((long long)R * (wave + 1) / nw);
+
+    // work-item generator; state is wave-uniform
+    int rb = r_lo - 64, cur = 0, mk = 0, bits = 0;
+    unsigned long long m = 0;
+    int nr = 0, ni = 0;
+    auto advance = [&]() -> bool {
+        for (;;) {
+            if (bits) {
+                ni = __builtin_ctz(bits);
+                bits &= bits - 1;
+                nr = rb + cur;
+                return true;
+            }
+            if (!m) {
+                if (rb + 64 >= r_hi) return false;
+                rb += 64;
+                mk = rb + lane < r_hi ? rowmask[(size_t)(rb + lane) * H + y] : 0;
+                m = __ballot(mk != 0);
+                continue;
+            }
+            cur = __builtin_ctzll(m);
+            m &= m - 1;
+            bits = __builtin_amdgcn_readlane(mk, cur);
+        }
+    };
+    struct Item { int rec; float rq; float v[KT]; };
+    auto fetch = [&](Item& it, int r, int i) {
+        it.rec = geo[(size_t)r * GEO + (lane & (GEO - 1))];          // the record, one int per lane
+        it.rq = rcp[(size_t)r * 64 + i * KT + (lane < KT ? lane : 0)];   // lanes 0..6: 1/n of the bin row's bins
+        const float* gr = gt + ((size_t)r * KK + i * KT) * C + cl;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) it.v[j] = gr[(size_t)j * C];    // 7 coalesced loads
+    };
+    auto add_item = [&](const Item& it) {
+        int j0[KT], w[KT];
+        float q[KT];
+        int wmax = 0;
+        bool regular = true;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            j0[j] = __builtin_amdgcn_readlane(it.rec, 2 * KT + j);
+            w[j] = __builtin_amdgcn_readlane(it.rec, 3 * KT + j) - j0[j];
+            wmax = w[j] > wmax ? w[j] : wmax;
+            q[j] = it.v[j] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, it.rq), j));
+        }
+#pragma unroll
+        for (int j = 0; j + 2 < KT; ++j) regular = regular && j0[j + 2] >= j0[j] + w[j];
+        auto batch = [&](auto sw_c, auto first_c) {                  // bins first, first+2, ..: SW slots each
+            constexpr int SW = decltype(sw_c)::value, FIRST = decltype(first_c)::value;
+            constexpr int NB = (KT - FIRST + 1) / 2;
+            float t[NB][SW];
+            int xo[NB][SW];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int s2 = 0; s2 < SW; ++s2) {
+                    const int j = FIRST + 2 * b;
+                    xo[b][s2] = (s2 < w[j] ? j0[j] + s2 : W) * RB_LD;   // wave-uniform; past the bin: dummy row
+                    t[b][s2] = acc[xo[b][s2]];
+                }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int s2 = 0; s2 < SW; ++s2) acc[xo[b][s2]] = t[b][s2] + q[FIRST + 2 * b];
+        };
+        using std::integral_constant;
+        if (regular && wmax <= 4) {
+            batch(integral_constant<int, 4>{}, integral_constant<int, 0>{});
+            batch(integral_constant<int, 4>{}, integral_constant<int, 1>{});
+        } else if (regular && wmax <= 8) {
+            batch(integral_constant<int, 8>{}, integral_constant<int, 0>{});
+            batch(integral_constant<int, 8>{}, integral_constant<int, 1>{});
+        } else {                                                     // tiny or very wide RoIs: pixel by pixel
+#pragma unroll 1
+            for (int j = 0; j < KT; ++j)
+#pragma unroll 1
+                for (int x = j0[j]; x < j0[j] + w[j]; ++x) acc[x * RB_LD] += q[j];
+        }
+    };
+    Item it[RC_PF];
+    bool ok[RC_PF];
+#pragma unroll
+    for (int s = 0; s < RC_PF; ++s) {
+        ok[s] = advance();
+        if (ok[s]) fetch(it[s], nr, ni);
+    }
+    while (ok[0]) {                                                  // slots are consumed round-robin = in item order
+#pragma unroll
+        for (int s = 0; s < RC_PF; ++s) {
+            if (ok[s]) {
+                add_item(it[s]);
+                ok[s] = advance();
+                if (ok[s]) fetch(it[s], nr, ni);
+            }
+        }
+    }
+    __syncthreads();
+    // gin[c0+ch][y][0..W): lanes along x, fixed-order sum of the waves' partial rows
+    const int nch = C - c0 < 64 ? C - c0 : 64;
+    for (int e = threadIdx.x; e < nch * W; e += blockDim.x) {
+        const int ch = e / W, x = e - ch * W;
+        const int o = x * RB_LD + ch;
+        float a = lds[o];
+        for (int wv = 1; wv < nw; ++wv) a += lds[(size_t)wv * per + o];
+        gin[((size_t)(c0 + ch) * H + y) * W + x] = a;
+    }
+}
+
 bool roipool_bwd_supported(int R, int C, int H, int W, int k)
 {
     return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && (C + 63) / 64 <= 65535 &&
-           (size_t)2 * W * RB_LD * sizeof(float) <= 64 * 1024;
+           (size_t)(W + 1) * RB_LD * sizeof(float) <= 64 * 1024;
 }
 
 size_t roipool_bwd_ws_bytes(int R, int C, int H, int W, int k)
 {
     if (!roipool_bwd_supported(R, C, H, W, k)) return 0;
-    return align256((size_t)R * C * KK * sizeof(float)) + geo_bytes(R);
+    return align256((size_t)R * C * KK * sizeof(float)) + geo_bytes(R) + align256((size_t)R * H) +
+           align256((size_t)R * 64 * sizeof(float));
 }
 
 int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int,
@@ -275,15 +437,16 @@ int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int
     hipLaunchKernelGGL(k_transpose_gout, dim3(R, (C + 63) / 64), dim3(256), 0, st, gout, gt, C);   // (R,C,49) -> (R,49,C)
     int rc = launch_status();
     if (rc != D2T_OK) return rc;
-    rc = roi_geom(rois, geo, R, H, W, st);
+    uint8_t* rowmask = reinterpret_cast<uint8_t*>(geo) + geo_bytes(R);
+    float* rcp = reinterpret_cast<float*>(rowmask + align256((size_t)R * H));
+    rc = roi_geom(rois, geo, rowmask, rcp, R, H, W, st);
     if (rc != D2T_OK) return rc;
     const dim3 grid(H, (C + 63) / 64);
-    if ((size_t)4 * W * RB_LD * sizeof(float) <= 64 * 1024)
-        hipLaunchKernelGGL(k_roipool_bwd_cl<4>, grid, dim3(256), (size_t)4 * W * RB_LD * sizeof(float), st,
-                           gt, geo, gin, R, C, H, W);
-    else
-        hipLaunchKernelGGL(k_roipool_bwd_cl<2>, grid, dim3(128), (size_t)2 * W * RB_LD * sizeof(float), st,
-                           gt, geo, gin, R, C, H, W);
+    const size_t acc_bytes = (size_t)(W + 1) * RB_LD * sizeof(float);
+    int waves = (int)(64 * 1024 / acc_bytes);                        // private accumulators that fit 64 KB of LDS
+    waves = waves > 4 ? 4 : waves;
+    hipLaunchKernelGGL(k_roipool_bwd_batched, grid, dim3(64 * waves), waves * acc_bytes, st,
+                       gt, geo, rowmask, rcp, gin, R, C, H, W);
     return launch_status();
 }
 
