@@ -12,9 +12,10 @@
 //    exactly one contiguous 12.5 KB run of the (R,C,7,7) output; they are transposed through LDS
 //    and stored as full 256-byte rows.
 //  * ROIPool backward (gather form): gradOut is transposed once to (R, 49, C); a workgroup owns
-//    (64 channels, one map row), each of its waves walks a share of the RoIs (wave-uniform
-//    geometry) and adds gradOut/n into an LDS accumulator [W][65] that it alone touches (plain
-//    read-add-write, one channel per lane); the partial rows are added in a fixed order.
+//    (64 channels, one map row), each of its waves walks a share of the RoIs -- work items come
+//    from a row-mask table, 64 RoIs per instruction, several in flight -- and adds gradOut/n into
+//    an LDS accumulator [W+1][65] that it alone touches (batched read-add-write, one channel per
+//    lane); the partial rows are added in a fixed order.
 //  * PSROIPool backward, phase 1: a workgroup owns one OUTPUT plane (t, bin) -- every plane has
 //    exactly R cells, so the grid is balanced whatever the many-to-one channel map
 //    ((t+1)*bin, ps_roipool_cuda.cu:58) does.  Its 4 waves own a quarter of the RoIs each and a
@@ -205,60 +206,8 @@ int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C
     return launch_status();
 }
 
-// ---------------------------------------------------------------------------------------
-// ROIPool backward, channel-last gather.  gt: gradOut transposed to (R, 49, C).
-// Workgroup = (map row y, 64 channels); wave w walks RoIs [w*R/NW, (w+1)*R/NW) and adds
-// gradOut/n into its own LDS accumulator [W][65] (lane = channel); the partial rows are added in
-// a fixed order and stored as 64 rows of gradIn.
-// ---------------------------------------------------------------------------------------
-constexpr int RB_LD = 65;
+constexpr int RB_LD = 65;                                            // accumulator row stride (floats): lanes along x read it conflict-free
 
-template <int RB_WAVES>                                              // 4 waves for W <= 63, 2 for W <= 126 (64 KB of LDS)
-__global__ void __launch_bounds__(RB_WAVES * 64)
-k_roipool_bwd_cl(const float* __restrict__ gt, const int32_t* __restrict__ geo, float* __restrict__ gin,
-                 int R, int C, int H, int W)
-{
-    extern __shared__ float accs[];                                  // [RB_WAVES][W][65]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int y = blockIdx.x, c0 = blockIdx.y * 64;
-    const int c = c0 + lane < C ? c0 + lane : C - 1;
-    float* acc = accs + (size_t)wave * W * RB_LD;
-    for (int x = 0; x < W; ++x) acc[x * RB_LD + lane] = 0.f;
-
-    const int r_lo = (int)((long long)R * wave / RB_WAVES), r_hi = (int)((long long)R * (wave + 1) / RB_WAVES);
-    for (int r = r_lo; r < r_hi; ++r) {
-        const int32_t* g = geo + (size_t)r * GEO;                    // wave-uniform: scalar loads
-        if (y < g[28] || y >= g[29]) continue;                       // row outside the RoI
-        const float* gr = gt + (size_t)r * KK * C + c;
-#pragma unroll
-        for (int i = 0; i < KT; ++i) {
-            const int i0 = g[i], i1 = g[KT + i];
-            if (y < i0 || y >= i1) continue;                         // uniform
-            float v[KT];
-#pragma unroll
-            for (int j = 0; j < KT; ++j) v[j] = gr[(size_t)(i * KT + j) * C];   // 7 coalesced loads in flight
-#pragma unroll
-            for (int j = 0; j < KT; ++j) {
-                const int j0 = g[2 * KT + j], j1 = g[3 * KT + j];
-                if (j1 <= j0) continue;
-                const float q = v[j] / static_cast<float>((i1 - i0) * (j1 - j0));     // roipool_cuda.cu:123
-                for (int x = j0; x < j1; ++x) acc[x * RB_LD + lane] += q;             // ascending (r,i,j)
-            }
-        }
-    }
-    __syncthreads();
-    // gin[c0+ch][y][0..W): lanes along x, fixed-order sum of the partial rows
-    const int nch = C - c0 < 64 ? C - c0 : 64;
-    const int per = W * RB_LD;
-    for (int e = threadIdx.x; e < nch * W; e += RB_WAVES * 64) {
-        const int ch = e / W, x = e - ch * W;
-        const int o = x * RB_LD + ch;
-        float a = accs[o];
-#pragma unroll
-        for (int w = 1; w < RB_WAVES; ++w) a += accs[w * per + o];   // fixed order
-        gin[((size_t)(c0 + ch) * H + y) * W + x] = a;
-    }
-}
 
 // batched (C x 49) -> (49 x C) transpose: block = one RoI x 64 channels
 __global__ void __launch_bounds__(256)
@@ -278,10 +227,11 @@ k_transpose_gout(const float* __restrict__ in, float* __restrict__ out, int C)
 }
 
 // ---------------------------------------------------------------------------------------
-// ROIPool backward, batched channel-last form (the default).  Decomposition as k_roipool_bwd_cl:
-// workgroup = (map row y, 64 channels), one channel per lane, each wave a share of the RoIs and a
-// private LDS accumulator [W+1][65] (row W is a dummy).  What differs is everything that made
-// that kernel a chain of latencies:
+// ROIPool backward, channel-last gather.  gt: gradOut transposed to (R, 49, C).
+// Workgroup = (map row y, 64 channels), one channel per lane; wave w walks RoIs [w*R/NW,
+// (w+1)*R/NW) and adds into its own LDS accumulator [W+1][65] (row W is a dummy); the partial rows
+// are added in a fixed order and stored as 64 rows of gradIn.  A first version walked the RoIs with
+// scalar loads and added pixel by pixel (269 us at config 3: a chain of latencies); this one:
 //  * work items (RoI r, bin row i containing y) come out of a row-mask table, 64 RoIs per
 //    instruction (lane = RoI): no scalar load per RoI;
 //  * RC_PF items are in flight: geometry record, 7 reciprocals and the 7 x 256 bytes of
