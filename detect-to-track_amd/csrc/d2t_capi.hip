@@ -190,10 +190,12 @@ static int check_ps(const void* fm, const void* rois, const void* out, int R, in
 }
 
 int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int k,
-                          void*, size_t, int, d2t_stream_t stream)
+                          void*, size_t, int impl, d2t_stream_t stream)
 {
     int rc = check_ps(fm, rois, out, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
+    if (impl != D2T_IMPL_GENERIC && R > 0 && tuned::psroipool_fwd_supported(R, nT, H, W, k))
+        return tuned::psroipool_fwd_f32(fm, rois, out, R, nT, H, W, k, as_stream(stream));
     return psroipool_fwd_generic<float>(fm, rois, out, R, nT, H, W, k, as_stream(stream));
 }
 

@@ -401,6 +401,61 @@ int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int
 }
 
 // ---------------------------------------------------------------------------------------
+// PSROIPool forward.  Workgroup = (RoI, 256 consecutive outputs (t, bin)).  The RoI's 49 cells
+// are evaluated once per workgroup (lanes 0..48, double-precision bin centres as the reference)
+// and shared through LDS instead of once per output; a thread then sums its cell row by row:
+// the pixels of a row are fetched with 8 independent (clamped) loads and added in ascending x, so
+// the dependent chain is the cell's rows, not its pixels.  The running sum sees the pixels in the
+// reference's order (ps_roipool_cuda.cu:60-66) and the guarded IEEE divide is kept: bit-identical.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_psroipool_fwd_roi(const float* __restrict__ fm, const float* __restrict__ rois, float* __restrict__ out,
+                    int nT, int H, int W)
+{
+    __shared__ int4 cells[KK];
+    const int r = blockIdx.x;
+    if (threadIdx.x < KK) {
+        const int i = threadIdx.x / KT, j = threadIdx.x - i * KT;
+        const Bounds c = psroi_cell<float>(rois + 4 * (size_t)r, i, j, H, W, KT);
+        cells[threadIdx.x] = make_int4(c.i0, c.i1, c.j0, c.j1);
+    }
+    __syncthreads();
+    const int e = blockIdx.y * 256 + threadIdx.x;                    // output (t, bin) of this RoI
+    if (e >= nT * KK) return;
+    const int t = e / KK, bin = e - t * KK;
+    const int4 c = cells[bin];
+    const float* ch = fm + (size_t)((t + 1) * bin) * H * W;          // ps_roipool_cuda.cu:58
+    const int w = c.w - c.z;
+    float acc = 0.f;
+    for (int y = c.x; y < c.y; ++y) {
+        const float* row = ch + y * W + c.z;
+        for (int x0 = 0; x0 < w; x0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = row[x0 + k < w ? x0 + k : w - 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (x0 + k < w) acc += v[k];                         // ascending x
+        }
+    }
+    const int n = (c.y - c.x) * w;
+    if (n > 0) acc /= static_cast<float>(n);                         // guarded divide, :68
+    out[(size_t)r * nT * KK + e] = acc;
+}
+
+bool psroipool_fwd_supported(int R, int nT, int H, int W, int k)
+{
+    return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && (nT * KK + 255) / 256 <= 65535;
+}
+
+int psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int,
+                      hipStream_t st)
+{
+    hipLaunchKernelGGL(k_psroipool_fwd_roi, dim3(R, (nT * KK + 255) / 256), dim3(256), 0, st, fm, rois, out, nT, H, W);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
 // Pixel ownership of the PSROIPool backward: 4 waves x bands of <= PX_ROWS rows, lane = column
 // (two column groups for maps wider than 64).
 // ---------------------------------------------------------------------------------------
