@@ -88,18 +88,17 @@ static void report(const char* name, float ms, int nchunks, int rows)
 
 int main()
 {
-    const int C = 2048, H = 38, W = 75, nchunks = 128;
-    const float* fm; float *fmw, *sink;
-    hipMalloc(&fmw, (size_t)C * H * W * 4); hipMalloc(&sink, 64);
-    hipMemset(fmw, 0, (size_t)C * H * W * 4);
-    fm = fmw;
-    RUN(0, 3, 19, "dma  3 waves 19 rows")
-    RUN(1, 3, 19, "regs 3 waves 19 rows")
-    RUN(0, 6, 19, "dma  6 waves 19 rows")
-    RUN(1, 6, 19, "regs 6 waves 19 rows")
-    RUN(0, 15, 35, "dma  15 waves 35 rows")
-    RUN(1, 15, 35, "regs 15 waves 35 rows")
-    RUN(0, 12, 19, "dma  12 waves 19 rows")
-    RUN(1, 12, 19, "regs 12 waves 19 rows")
+    const int C = 2048, H = 38, nchunks = 128;
+    float *fmw, *sink;
+    hipMalloc(&fmw, (size_t)C * H * 80 * 4); hipMalloc(&sink, 64);
+    hipMemset(fmw, 0, (size_t)C * H * 80 * 4);
+    const float* fm = fmw;
+    for (int W : {75, 63, 64, 80}) {
+        printf("W = %d\n", W);
+        RUN(0, 3, 19, "dma  3 waves 19 rows")
+        RUN(1, 3, 19, "regs 3 waves 19 rows")
+        RUN(0, 15, 35, "dma  15 waves 35 rows")
+        RUN(1, 15, 35, "regs 15 waves 35 rows")
+    }
     return 0;
 }

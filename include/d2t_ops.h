@@ -63,9 +63,12 @@ enum {
 int         d2t_version(void);
 const char* d2t_error_string(int code);
 
-/* Implementation selector for the f32 correlation kernels (per call, no global state):
- *   D2T_IMPL_AUTO    the tuned gfx950 path when its preconditions hold, else generic
- *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)     */
+/* Implementation selector of the f32 entry points (per call, no global state):
+ *   D2T_IMPL_AUTO    the tuned gfx950 path when its preconditions hold and it is the faster one
+ *                    (ROIPool forward with fewer than 32 RoIs takes the generic kernel), else generic
+ *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)
+ *   D2T_IMPL_MFMA    the tuned path, demanded: correlation returns D2T_EINVAL when its preconditions
+ *                    (d_max = 8, stride 1, W >= 20) do not hold; the pooling ops fall back to generic */
 enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2 };
 
 /* ---------------- PointwiseCorrelation ---------------- */

@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = dict(rtol=1e-5, atol=1e-5)
-GENERIC, AUTO = 1, 0
+GENERIC, TUNED = 1, 2         # D2T_IMPL_MFMA: the tuned kernels, demanded (no silent generic dispatch)
 
 
 def _rois(rng, R):
@@ -52,10 +52,10 @@ def test_correlation_tuned_equals_generic(case):
     fm0 = torch.rand(B, C, H, W, generator=g).to(DEV)
     fm1 = torch.rand(B, C, H, W, generator=g).to(DEV)
     gout = torch.rand(B, H, W, 17, 17, generator=g).to(DEV)
-    out_t = _ext.pointwise_correlation_forward(fm0, fm1, 8, 1, AUTO)
+    out_t = _ext.pointwise_correlation_forward(fm0, fm1, 8, 1, TUNED)
     out_g = _ext.pointwise_correlation_forward(fm0, fm1, 8, 1, GENERIC)
     assert torch.equal(out_t, out_g), f"max |delta| {(out_t - out_g).abs().max().item()}"
-    t0, t1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, AUTO)
+    t0, t1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, TUNED)
     g0, g1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, GENERIC)
     torch.testing.assert_close(t0, g0, **TOL)
     torch.testing.assert_close(t1, g1, **TOL)
@@ -78,10 +78,10 @@ def test_roipool_tuned_equals_generic(case):
     fm = torch.from_numpy(rng.random((C, H, W), dtype=np.float32)).to(DEV)
     gout = torch.from_numpy(rng.random((R, C, 7, 7), dtype=np.float32)).to(DEV)
     rois = _rois(rng, R)
-    out_t = _ext.roipool_forward(fm, rois, 7, AUTO)
+    out_t = _ext.roipool_forward(fm, rois, 7, TUNED)
     out_g = _ext.roipool_forward(fm, rois, 7, GENERIC)
     assert torch.equal(torch.nan_to_num(out_t, nan=-7.0), torch.nan_to_num(out_g, nan=-7.0))   # NaN pattern included
-    gin_t = _ext.roipool_backward(gout, rois, H, W, AUTO)
+    gin_t = _ext.roipool_backward(gout, rois, H, W, TUNED)
     gin_g = _ext.roipool_backward(gout, rois, H, W, GENERIC)
     torch.testing.assert_close(gin_t, gin_g, **TOL)
 
@@ -103,9 +103,9 @@ def test_ps_roipool_tuned_equals_generic(case):
     fm = torch.from_numpy(rng.random((nT * 49, H, W), dtype=np.float32)).to(DEV)
     gout = torch.from_numpy(rng.random((R, nT, 7, 7), dtype=np.float32)).to(DEV)
     rois = _rois(rng, R)
-    out_t = _ext.ps_roipool_forward(fm, rois, nT, 7, AUTO)
+    out_t = _ext.ps_roipool_forward(fm, rois, nT, 7, TUNED)
     out_g = _ext.ps_roipool_forward(fm, rois, nT, 7, GENERIC)
     assert torch.equal(out_t, out_g), f"max |delta| {(out_t - out_g).abs().max().item()}"
-    gin_t = _ext.ps_roipool_backward(gout, rois, H, W, AUTO)
+    gin_t = _ext.ps_roipool_backward(gout, rois, H, W, TUNED)
     gin_g = _ext.ps_roipool_backward(gout, rois, H, W, GENERIC)
     torch.testing.assert_close(gin_t, gin_g, **TOL)
