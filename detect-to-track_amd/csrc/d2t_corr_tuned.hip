@@ -722,18 +722,20 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
 // The same kernel with the workgroup width as a template parameter (instantiated for 4 waves = 64
 // channels), used when 16-wave workgroups would leave most CUs idle (B = 1 shapes of the real
 // model).  Kept separate from the 16-wave kernel above, whose code generation it perturbs (+6 %).
-template <int ST_WAVES>
-__global__ void __launch_bounds__(ST_WAVES * 64)
+template <int ST_WAVES, int PROD_WAVES>                          // MFMA waves (16 channels each) + waves that only produce G
+__global__ void __launch_bounds__((ST_WAVES + PROD_WAVES) * 64)
 k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
                  float* __restrict__ g0, float* __restrict__ g1,
                  int B, int C, int H, int W, int tiles_i, int tiles_j)
 {
-    constexpr int ST_THREADS = ST_WAVES * 64;
+    constexpr int ST_THREADS = (ST_WAVES + PROD_WAVES) * 64;
     constexpr int ST_CH = ST_WAVES * 16;                             // channels per workgroup pass
     constexpr int Q_PER_THREAD = 2048 / ST_THREADS;                  // ring quads per thread (2 or 8)
     __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 64 KB
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mfma_wave = PROD_WAVES == 0 || wave < ST_WAVES;       // wave-uniform
     const int bid = xcd_remap(blockIdx.x, gridDim.x);                // (role, b) pairs stay on one XCD
     const int tj = bid % tiles_j, b = (bid / tiles_j) % B, role = bid / (tiles_j * B);
     const int j0 = tj * TP, HW = H * W;
@@ -743,7 +745,7 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
     float* gx = role ? g1 : g0;
     const float* gb = gout + (size_t)b * HW * CELLS;
 
-    const int cw = blockIdx.y * ST_CH + wave * 16;                   // first channel of this wave's c-tile
+    const int cw = blockIdx.y * ST_CH + (mfma_wave ? wave : 0) * 16;                   // first channel of this wave's c-tile
     const int cl = cw + n < C ? cw + n : C - 1;                      // lane's channel (clamped; never stored)
     const float* sp = S + ((size_t)b * C + cl) * HW + col0;
 
@@ -789,6 +791,7 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
     for (int ss = 0; ss < tiles_i; ++ss) {
         const int cur = ss & 1;
         const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
+        if (mfma_wave) {
 #pragma unroll
         for (int q = 0; q < KB_SS; ++q) {
             const f32x4 a4 = av;
@@ -802,6 +805,7 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
                 for (int a = 0; a < NACT; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
             }
         }
+        }
         // hand super-step ss+1's G (requested a whole super-step ago) to the other buffer, then
         // request ss+2's: these loads are the YOUNGEST in the queue, so no FM load of the next
         // super-step has to wait behind them (vmcnt retires in order)
@@ -810,13 +814,15 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
 #pragma unroll
         for (int k = 0; k < Q_PER_THREAD; ++k) gn[k] = strip_quad_load(gb, qd[k], ss + 2, gstep, gdp);   // past the map: zeros
         __syncthreads();
-        store_tile(acc[0], ss - 2);                                  // complete after its 5th super-step
+        if (mfma_wave) store_tile(acc[0], ss - 2);                   // complete after its 5th super-step
 #pragma unroll
         for (int a = 0; a + 1 < NACT; ++a) acc[a] = acc[a + 1];
         acc[NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    store_tile(acc[0], tiles_i - 2);                                 // their remaining super-steps lie below the map
-    store_tile(acc[1], tiles_i - 1);
+    if (mfma_wave) {
+        store_tile(acc[0], tiles_i - 2);                             // their remaining super-steps lie below the map
+        store_tile(acc[1], tiles_i - 1);
+    }
 }
 
 bool corr_bwd_supported(int B, int C, int H, int W, int d, int s)
@@ -836,8 +842,11 @@ int corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g
     if (wide >= 100)
         hipLaunchKernelGGL(k_corr_bwd_strip, dim3(2 * B * tiles_j, (C + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
                            gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    else if (2LL * B * tiles_j * ((C + 63) / 64) <= 256)            // at most one per CU: 4 MFMA waves (64 channels)
+        hipLaunchKernelGGL((k_corr_bwd_strip_n<4, 4>), dim3(2 * B * tiles_j, (C + 63) / 64), dim3(512), 0, st,
+                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);   // + 4 waves that only produce G
     else                                                             // small grids: 4 waves (64 channels) per workgroup
-        hipLaunchKernelGGL(k_corr_bwd_strip_n<4>, dim3(2 * B * tiles_j, (C + 63) / 64), dim3(256), 0, st,
+        hipLaunchKernelGGL((k_corr_bwd_strip_n<4, 0>), dim3(2 * B * tiles_j, (C + 63) / 64), dim3(256), 0, st,
                            gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
     return launch_status();
 }
