@@ -10,16 +10,21 @@ forward + backward at BASELINE.json's metric shape (B=8, C=256, 38x63, d_max=8, 
 called through the C ABI of libd2t_ops.so exactly as the autograd Function calls it (same entry
 points, caller-allocated outputs, torch's current stream).  Inputs are resident in HBM before the
 timed region.  `--sets` independent buffer sets are rotated (default: > 512 MiB footprint) so the
-256 MiB Infinity Cache does not stand in for HBM.
+256 MiB Infinity Cache does not stand in for HBM; every set is touched once during setup (page
+tables, clocks) before the W warmup steps.
 
 Multi-GPU: the path shards by frame-pair with no exchange step, so every rank runs the same
 per-GPU workload on its own shard (weak scaling) with NO data-path collective; ranks only meet at
 the timing barriers and the MAX-over-ranks reduction of the elapsed time.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+
+The rank skeleton (`run`) takes its device layer as an object: `HipDevice` (below) is the real
+one; tests/bench_stub_main.py passes a CPU stand-in so that the launch / init / barrier /
+MAX-over-ranks / print-on-rank-0 path runs under torch.distributed.run with gloo on a box
+without GPUs (tests/test_sharding_gloo.py).  Nothing in this file selects a stub by itself.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -31,6 +36,7 @@ sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* dense f32 = f32 vector peak
+METRIC = "PointwiseCorrelation fwd+bwd Gvox/s (and % HBM roofline) at B=8 C=256 38×63 d=8"
 
 WORKLOADS = {
     # BASELINE.json metric shape ("north star")
@@ -72,12 +78,13 @@ def host_threads():
 
 def cpu_baseline(cfg, counts, budget_s=12.0):
     """Time the CPU oracle (a port: the reference has no CPU path, common/cpp_common.hpp:1) on
-    the same workload with all host threads.  Checker code, used here ONLY as a baseline."""
+    the same workload: all host threads (the headline `value`) and one thread on a
+    quarter-batch sample.  Checker code, used here ONLY as a baseline."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import numpy as np
     threads = host_threads()
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     import oracle as O
+    O.set_threads(threads)
     rng = np.random.default_rng(0)
     shp = (cfg["B"], cfg["C"], cfg["H"], cfg["W"])
     cw = 2 * cfg["d"] + 1
@@ -92,9 +99,19 @@ def cpu_baseline(cfg, counts, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or reps >= 50:
             break
+    # one thread: a bounded sample (the first nb pairs) of the same batch, one fwd+bwd
+    nb = max(1, cfg["B"] // 4)
+    O.set_threads(1)
+    t1 = time.perf_counter()
+    O.corr_fwd(fm0[:nb], fm1[:nb], cfg["d"], cfg["s"])
+    O.corr_bwd(g[:nb], fm0[:nb], fm1[:nb], cfg["d"], cfg["s"])
+    el1 = time.perf_counter() - t1
+    O.set_threads(threads)
     return dict(value=counts["vox"] * reps / el / 1e9, unit="Gvox/s", cores=threads, kind="port",
                 sample=f"{reps} full steps (fwd+bwd, B={cfg['B']}) of the same workload in {el:.1f} s, "
-                       f"oracle/libd2t_oracle.so with OpenMP over {threads} threads")
+                       f"oracle/libd2t_oracle.so with OpenMP over {threads} threads",
+                single_thread=dict(value=counts["vox"] * nb / cfg["B"] / el1 / 1e9, unit="Gvox/s", cores=1,
+                                   sample=f"1 step (fwd+bwd) on the first {nb} of {cfg['B']} pairs in {el1:.1f} s"))
 
 
 def rank_env():
@@ -119,104 +136,133 @@ def whole_job_value(units_per_rank_step, world, steps, elapsed_s):
     return world * units_per_rank_step * steps / elapsed_s
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="corr_B8_C256_38x63_d8", choices=sorted(WORKLOADS))
-    ap.add_argument("--sets", type=int, default=0, help="rotated buffer sets (0 = enough for > 512 MiB)")
-    ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 tuned only")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class HipDevice:
+    """The device layer of the benchmark: buffers in HBM, the two C-ABI calls, HIP events on the
+    launch stream, RCCL process group.  (`torch.distributed` backend "nccl" is RCCL on ROCm.)"""
+    backend = "nccl"
 
-    import torch
+    def __init__(self, local_rank, impl):
+        import torch
+        from detect_to_track.models import _native       # raises ImportError if the HIP library is missing
+        self.torch, self.native, self.lib, self.impl = torch, _native, _native.lib, impl
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+
+    def init_process_group(self):
+        import torch.distributed as dist
+        dist.init_process_group(self.backend, device_id=self.dev)
+
+    def setup(self, cfg, n_sets, seed):
+        torch = self.torch
+        B, C, H, W, d, s = (cfg[k] for k in "BCHWds")
+        cw = 2 * d + 1
+        torch.manual_seed(seed)                                # per-rank shard of synthetic frame pairs
+        self.cfg = cfg
+        self.sets = [dict(fm0=torch.rand(B, C, H, W, device=self.dev), fm1=torch.rand(B, C, H, W, device=self.dev),
+                          gout=torch.rand(B, H, W, cw, cw, device=self.dev),
+                          out=torch.empty(B, H, W, cw, cw, device=self.dev),
+                          g0=torch.empty(B, C, H, W, device=self.dev), g1=torch.empty(B, C, H, W, device=self.dev))
+                     for _ in range(n_sets)]
+        self.wsf_n = self.lib.d2t_corr_fwd_workspace_bytes(B, C, H, W, d, s, 4)
+        self.wsb_n = self.lib.d2t_corr_bwd_workspace_bytes(B, C, H, W, d, s, 4)
+        self.wsf = torch.empty(max(self.wsf_n, 1), dtype=torch.uint8, device=self.dev)
+        self.wsb = torch.empty(max(self.wsb_n, 1), dtype=torch.uint8, device=self.dev)
+        self.stream = torch.cuda.current_stream(self.dev)
+        self.sh = self.stream.cuda_stream
+
+    def _check(self, rc):
+        if rc:
+            raise RuntimeError(self.native.error_string(rc).decode())
+
+    def fwd(self, i):
+        z, c = self.sets[i], self.cfg
+        self._check(self.lib.d2t_corr_fwd_f32(z["fm0"].data_ptr(), z["fm1"].data_ptr(), z["out"].data_ptr(),
+                                              c["B"], c["C"], c["H"], c["W"], c["d"], c["s"],
+                                              self.wsf.data_ptr(), self.wsf_n, self.impl, self.sh))
+
+    def bwd(self, i):
+        z, c = self.sets[i], self.cfg
+        self._check(self.lib.d2t_corr_bwd_f32(z["gout"].data_ptr(), z["fm0"].data_ptr(), z["fm1"].data_ptr(),
+                                              z["g0"].data_ptr(), z["g1"].data_ptr(),
+                                              c["B"], c["C"], c["H"], c["W"], c["d"], c["s"],
+                                              self.wsb.data_ptr(), self.wsb_n, self.impl, self.sh))
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def new_event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def record(self, ev):
+        ev.record(self.stream)                                 # on the stream the kernels are launched on
+
+    def elapsed_ms(self, e0, e1):
+        return e0.elapsed_time(e1)
+
+    def reduce_device(self):
+        return self.dev
+
+
+def run(args, device):
+    """The rank skeleton: init, setup, W warmup steps, EXACTLY K timed steps between barriers,
+    MAX over ranks, one JSON line on rank 0."""
     import torch.distributed as dist
-    from detect_to_track.models import _native           # raises ImportError if the HIP library is missing
 
-    rank, world, local = rank_env()
+    rank, world, _ = rank_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        device.init_process_group()
 
     cfg = WORKLOADS[args.workload]
-    B, C, H, W, d, s = (cfg[k] for k in "BCHWds")
-    cw = 2 * d + 1
+    B, C, H, W = (cfg[k] for k in "BCHW")
     cnt = corr_counts(**cfg)
     set_bytes = 4 * (B * C * H * W * 4) + 2 * (cnt["vox"] * 4)            # fm0, fm1, g0, g1 + out, gout
     n_sets = args.sets or max(2, -(-(512 << 20) // set_bytes) + 1)
-
-    torch.manual_seed(rank)                                # per-rank shard of synthetic frame pairs
-    sets = []
-    for _ in range(n_sets):
-        sets.append(dict(
-            fm0=torch.rand(B, C, H, W, device=dev), fm1=torch.rand(B, C, H, W, device=dev),
-            gout=torch.rand(B, H, W, cw, cw, device=dev),
-            out=torch.empty(B, H, W, cw, cw, device=dev),
-            g0=torch.empty(B, C, H, W, device=dev), g1=torch.empty(B, C, H, W, device=dev)))
-    lib = _native.lib
-    wsf_n = lib.d2t_corr_fwd_workspace_bytes(B, C, H, W, d, s, 4)
-    wsb_n = lib.d2t_corr_bwd_workspace_bytes(B, C, H, W, d, s, 4)
-    wsf = torch.empty(max(wsf_n, 1), dtype=torch.uint8, device=dev)
-    wsb = torch.empty(max(wsb_n, 1), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    sh = stream.cuda_stream
-
-    def fwd(z):
-        rc = lib.d2t_corr_fwd_f32(z["fm0"].data_ptr(), z["fm1"].data_ptr(), z["out"].data_ptr(),
-                                  B, C, H, W, d, s, wsf.data_ptr(), wsf_n, args.impl, sh)
-        if rc:
-            raise RuntimeError(_native.error_string(rc).decode())
-
-    def bwd(z):
-        rc = lib.d2t_corr_bwd_f32(z["gout"].data_ptr(), z["fm0"].data_ptr(), z["fm1"].data_ptr(),
-                                  z["g0"].data_ptr(), z["g1"].data_ptr(),
-                                  B, C, H, W, d, s, wsb.data_ptr(), wsb_n, args.impl, sh)
-        if rc:
-            raise RuntimeError(_native.error_string(rc).decode())
+    device.setup(cfg, n_sets, seed=rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        device.synchronize()
 
+    for i in range(n_sets):                                    # setup: touch every buffer set once
+        device.fwd(i)
+        device.bwd(i)
     for i in range(args.warmup):
-        z = sets[i % n_sets]
-        fwd(z)
-        bwd(z)
+        device.fwd(i % n_sets)
+        device.bwd(i % n_sets)
 
     K = args.steps
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * K)]   # recorded on the launch stream
+    ev = [device.new_event() for _ in range(3 * K)]
     barrier()
     t0 = time.perf_counter()
     for i in range(K):
-        z = sets[(args.warmup + i) % n_sets]
-        ev[3 * i].record(stream)
-        fwd(z)
-        ev[3 * i + 1].record(stream)
-        bwd(z)
-        ev[3 * i + 2].record(stream)
+        z = (args.warmup + i) % n_sets
+        device.record(ev[3 * i])
+        device.fwd(z)
+        device.record(ev[3 * i + 1])
+        device.bwd(z)
+        device.record(ev[3 * i + 2])
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t_fwd = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K)) / K * 1e-3      # s per launch
-    t_bwd = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)) / K * 1e-3
-    elapsed = max_over_ranks(elapsed, world, dev)
+    us_fwd = [device.elapsed_ms(ev[3 * i], ev[3 * i + 1]) * 1e3 for i in range(K)]
+    us_bwd = [device.elapsed_ms(ev[3 * i + 1], ev[3 * i + 2]) * 1e3 for i in range(K)]
+    elapsed = max_over_ranks(elapsed, world, device.reduce_device())
 
     if rank == 0:
         ms = elapsed / K * 1e3
         value = whole_job_value(cnt["vox"], world, K, elapsed) / 1e9
 
-        def roof(name, t, nbytes, flops):
-            return dict(kernel=name, us=t * 1e6,
+        def roof(name, us, nbytes, flops):
+            t = sum(us) / len(us) * 1e-6                       # mean launch duration, s
+            return dict(kernel=name, us=t * 1e6, us_min=min(us), us_max=max(us),
                         hbm=dict(achieved=nbytes / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=nbytes / t / 1e9 / HBM_PEAK_GBS),
                         mfma=dict(achieved=flops / t / 1e12, peak=FP32_MATRIX_PEAK_TF, unit="TFLOP/s",
                                   frac=flops / t / 1e12 / FP32_MATRIX_PEAK_TF))
-        kernels = [roof("corr_fwd", t_fwd, cnt["fwd_bytes"], cnt["fwd_flops"]),
-                   roof("corr_bwd", t_bwd, cnt["bwd_bytes"], cnt["bwd_flops"])]
+        kernels = [roof("corr_fwd", us_fwd, cnt["fwd_bytes"], cnt["fwd_flops"]),
+                   roof("corr_bwd", us_bwd, cnt["bwd_bytes"], cnt["bwd_flops"])]
         dom = max(kernels, key=lambda r: r["us"])
         # The correlation is f32-FMA-bound at this shape (AI 34-42 F/B vs a 19.7 F/B ridge,
         # SURVEY.md F10), so the binding roof of the dominant kernel is the f32 matrix/vector peak;
@@ -228,8 +274,9 @@ def main():
                 traffic = json.loads(tfile.read_text()).get(args.workload, {}).get(dom["kernel"])
             except Exception:
                 traffic = None
+        t_dev = (kernels[0]["us"] + kernels[1]["us"]) * 1e-3
         line = {
-            "metric": "PointwiseCorrelation fwd+bwd Gvox/s (and % HBM roofline) at B=8 C=256 38×63 d=8",
+            "metric": METRIC,
             "value": value, "unit": "Gvox/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -239,10 +286,10 @@ def main():
                          "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s", "frac": dom["mfma"]["frac"],
                          "traffic": traffic, "launch_us": dom["us"]},
             "kernels": kernels,
-            "fwd_gvox_per_s": cnt["vox"] / t_fwd / 1e9, "bwd_gvox_per_s": cnt["vox"] / t_bwd / 1e9,
+            "fwd_gvox_per_s": cnt["vox"] / kernels[0]["us"] / 1e3, "bwd_gvox_per_s": cnt["vox"] / kernels[1]["us"] / 1e3,
             "pct_hbm_roofline_fwd": 100 * kernels[0]["hbm"]["frac"],
             "pct_hbm_roofline_bwd": 100 * kernels[1]["hbm"]["frac"],
-            "host_ms_per_step_minus_device": ms - (t_fwd + t_bwd) * 1e3,
+            "host_ms_per_step_minus_device": ms - t_dev,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, cnt)
@@ -251,6 +298,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="corr_B8_C256_38x63_d8", choices=sorted(WORKLOADS))
+    ap.add_argument("--sets", type=int, default=0, help="rotated buffer sets (0 = enough for > 512 MiB)")
+    ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 tuned only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    run(args, HipDevice(rank_env()[2], args.impl))
 
 
 if __name__ == "__main__":

@@ -615,6 +615,56 @@ __device__ __forceinline__ f32x4 strip_quad_load(const float* __restrict__ gb, c
     return v;
 }
 
+
+// ------------------------------------------------------------------------------------
+// Non-finite inputs.  The MFMA form multiplies window slots a tile pixel does not own by an exact
+// 0 weight; an Inf / NaN in the feature map S then turns that product into NaN and poisons the
+// whole accumulator row (channel) of the tile, including pixels whose own window does not contain
+// the bad value -- the reference (pointwise_correlation_cuda.cu:154-171) only ever touches a
+// pixel's own window.  Every poisoned element is itself non-finite, so a wave that stored a
+// non-finite value recomputes ITS region (16 channels x the strip) in the reference's own form at
+// the end of the kernel: gather loops, fused multiply-add chain, ascending order -- the same
+// arithmetic as the type-generic kernel.  Cold code: never runs on finite inputs.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool nonfinite4(const f32x4& d)
+{
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[0]), __builtin_fabsf(d[1])),
+                                    __builtin_fmaxf(__builtin_fabsf(d[2]), __builtin_fabsf(d[3])));
+    return !(m <= 3.4028234663852886e38f) || d[0] != d[0] || d[1] != d[1] || d[2] != d[2] || d[3] != d[3];
+}
+
+__device__ __attribute__((noinline)) void strip_repair(int role, int lane, const float* __restrict__ gb,
+                                                       const float* __restrict__ Sb, float* __restrict__ gxb,
+                                                       int cw, int C, int H, int W, int j0)
+{
+    const int HW = H * W;
+    for (int e = lane; e < 16 * H * TP; e += 64) {
+        const int c = cw + e / (H * TP), rem = e % (H * TP), y = rem / TP, x = j0 + rem % TP;
+        if (c >= C || x >= W) continue;
+        const float* sc = Sb + (size_t)c * HW;
+        float a = 0.f;
+        if (role == 0) {                                             // centre (y,x): walk its window of FM1
+            const int lo_i = y - DT > 0 ? y - DT : 0, hi_i = y + DT < H ? y + DT : H;
+            const int lo_j = x - DT > 0 ? x - DT : 0, hi_j = x + DT < W ? x + DT : W;
+            const float* gc = gb + (size_t)(y * W + x) * CELLS;
+            for (int di = lo_i; di < hi_i; ++di)
+                for (int dj = lo_j; dj < hi_j; ++dj)
+                    a = __builtin_fmaf(gc[(di - y + DT) * CW + (dj - x + DT)], sc[di * W + dj], a);
+        } else {                                                     // displaced (y,x): the centres that reach it
+            const int i_lo = y - DT > 0 ? y - DT : 0, i_hi = y + DT < H - 1 ? y + DT : H - 1;
+            const int j_lo = x - DT > 0 ? x - DT : 0, j_hi = x + DT < W - 1 ? x + DT : W - 1;
+            for (int i = i_lo; i <= i_hi; ++i) {
+                if (!corr_axis_hit(i, y, H, DT, 1)) continue;
+                for (int j = j_lo; j <= j_hi; ++j) {
+                    if (!corr_axis_hit(j, x, W, DT, 1)) continue;
+                    a = __builtin_fmaf(gb[((size_t)(i * W + j) * CW + (y - i + DT)) * CW + (x - j + DT)], sc[i * W + j], a);
+                }
+            }
+        }
+        gxb[(size_t)c * HW + y * W + x] = a;
+    }
+}
+
 __global__ void __launch_bounds__(ST_THREADS)
 k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
                  float* __restrict__ g0, float* __restrict__ g1,
@@ -647,9 +697,11 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
         rho = rho < H ? rho : H - 1;
         return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
     };
+    bool bad = false;                                                // this lane stored a non-finite value
     auto store_tile = [&](const f32x4& d, int u) {
         const int i = 4 * u + (n >> 2), j = j0 + (n & 3);
         if (u < 0 || u >= tiles_i || i >= H || j >= W) return;
+        bad = bad || nonfinite4(d);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = cw + 4 * g + r;
@@ -717,6 +769,8 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
     }
     store_tile(acc[0], tiles_i - 2);                                 // their remaining super-steps lie below the map
     store_tile(acc[1], tiles_i - 1);
+    if (__builtin_expect(__any(bad), 0))                             // cold: non-finite inputs only
+        strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0);
 }
 
 // The same kernel with the workgroup width as a template parameter (instantiated for 4 waves = 64
@@ -760,9 +814,11 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
         rho = rho < H ? rho : H - 1;
         return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
     };
+    bool bad = false;                                                // this lane stored a non-finite value
     auto store_tile = [&](const f32x4& d, int u) {
         const int i = 4 * u + (n >> 2), j = j0 + (n & 3);
         if (u < 0 || u >= tiles_i || i >= H || j >= W) return;
+        bad = bad || nonfinite4(d);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = cw + 4 * g + r;
@@ -822,6 +878,8 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
     if (mfma_wave) {
         store_tile(acc[0], tiles_i - 2);                             // their remaining super-steps lie below the map
         store_tile(acc[1], tiles_i - 1);
+        if (__builtin_expect(__any(bad), 0))                         // cold: non-finite inputs only
+            strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0);
     }
 }
 

@@ -30,7 +30,8 @@ k_corr_fwd_generic(const T* __restrict__ fm0, const T* __restrict__ fm1, T* __re
     const int cw = 2 * d + 1;
     const int plane = H * W;
     const int total = B * plane * cw * cw;
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+    for (long long i64 = (long long)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlock) {
+        const int idx = static_cast<int>(i64);
         const int cj = idx % cw;
         const int ci = (idx / cw) % cw;
         const int pix = idx / (cw * cw);
@@ -64,7 +65,8 @@ k_corr_bwd_generic(const T* __restrict__ gout, const T* __restrict__ fm0, const 
     const int cw = 2 * d + 1;
     const int plane = H * W;
     const int total = B * C * plane;
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+    for (long long i64 = (long long)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlock) {
+        const int idx = static_cast<int>(i64);
         const int x = idx % W, y = (idx / W) % H;
         const int b = idx / (C * plane);
         const size_t chan = (size_t)(idx / plane) * plane;       // offset of plane (b,c)
@@ -103,7 +105,8 @@ __global__ void k_corr_mask(uint8_t* __restrict__ mask, int H, int W, int d, int
 {
     const int cw = 2 * d + 1;
     const int total = H * W * cw * cw;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (long long i64 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * blockDim.x) {
+        const int idx = static_cast<int>(i64);
         const int cj = idx % cw, ci = (idx / cw) % cw, pix = idx / (cw * cw);
         const int j = pix % W, i = pix / W;
         mask[idx] = (corr_axis_hit(i, i - d + ci, H, d, s) && corr_axis_hit(j, j - d + cj, W, d, s)) ? 1 : 0;
@@ -120,7 +123,8 @@ k_roipool_fwd_generic(const T* __restrict__ fm, const T* __restrict__ rois, T* _
                       int R, int C, int H, int W, int k)
 {
     const int total = R * C * k * k;
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+    for (long long i64 = (long long)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlock) {
+        const int idx = static_cast<int>(i64);
         const int j = idx % k, i = (idx / k) % k, c = (idx / (k * k)) % C, r = idx / (k * k * C);
         const Bounds bb = roi_bin<T>(rois + 4 * r, i, j, H, W, k);
         const T* ch = fm + (size_t)c * H * W;
@@ -138,7 +142,8 @@ __global__ void k_roipool_bins(const T* __restrict__ rois, int32_t* __restrict__
                                int R, int H, int W, int k, int position_sensitive)
 {
     const int total = R * k * k;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (long long i64 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * blockDim.x) {
+        const int idx = static_cast<int>(i64);
         const int j = idx % k, i = (idx / k) % k, r = idx / (k * k);
         const Bounds bb = position_sensitive ? psroi_cell<T>(rois + 4 * r, i, j, H, W, k)
                                              : roi_bin<T>(rois + 4 * r, i, j, H, W, k);
@@ -159,13 +164,19 @@ k_roipool_bwd_generic(const T* __restrict__ gout, const int32_t* __restrict__ bi
 {
     const int total = C * H * W;
     const int4* bt = reinterpret_cast<const int4*>(bins);
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+    for (long long i64 = (long long)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlock) {
+        const int idx = static_cast<int>(i64);
         const int x = idx % W, y = (idx / W) % H, c = idx / (H * W);
         T acc = T(0);
         for (int r = 0; r < R; ++r) {
             const int4* br = bt + (size_t)r * k * k;
-            // quick reject on the RoI's overall extent
-            if (y < br[0].x || y >= br[(k - 1) * k].y || x < br[0].z || x >= br[k - 1].w) continue;
+            // quick reject on the RoI's overall extent.  Bin edges are monotone in the bin index but
+            // DEcreasing for a RoI of negative height / width (its bins run in reverse order and
+            // one-pixel bins stay non-empty, roipool_cuda.cu:41-50), so take min / max of both ends.
+            const int4 bf = br[0], bl = br[k * k - 1];
+            const int y_lo = bf.x < bl.x ? bf.x : bl.x, y_hi = bf.y > bl.y ? bf.y : bl.y;
+            const int x_lo = bf.z < bl.z ? bf.z : bl.z, x_hi = bf.w > bl.w ? bf.w : bl.w;
+            if (y < y_lo || y >= y_hi || x < x_lo || x >= x_hi) continue;
             const T* gr = gout + ((size_t)r * C + c) * k * k;
             for (int i = 0; i < k; ++i) {
                 const int4 bi = br[i * k];
@@ -192,7 +203,8 @@ k_psroipool_fwd_generic(const T* __restrict__ fm, const T* __restrict__ rois, T*
                         int R, int nT, int H, int W, int k)
 {
     const int total = R * nT * k * k;
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+    for (long long i64 = (long long)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlock) {
+        const int idx = static_cast<int>(i64);
         const int j = idx % k, i = (idx / k) % k, t = (idx / (k * k)) % nT, r = idx / (k * k * nT);
         const Bounds bb = psroi_cell<T>(rois + 4 * r, i, j, H, W, k);
         const T* ch = fm + (size_t)((t + 1) * (i * k + j)) * H * W;
@@ -209,7 +221,8 @@ k_psroipool_fwd_generic(const T* __restrict__ fm, const T* __restrict__ rois, T*
 __global__ void k_psroipool_channels(int32_t* __restrict__ ch, int nT, int k)
 {
     const int total = nT * k * k;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    for (long long i64 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * blockDim.x) {
+        const int idx = static_cast<int>(i64);
         const int j = idx % k, i = (idx / k) % k, t = idx / (k * k);
         ch[idx] = (t + 1) * (i * k + j);
     }
@@ -229,7 +242,8 @@ k_psroipool_bwd_generic(const T* __restrict__ gout, const int32_t* __restrict__ 
     const int kk = k * k;
     const int total = nT * kk * H * W;
     const int4* ct = reinterpret_cast<const int4*>(cells);
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < total; idx += gridDim.x * kBlock) {
+    for (long long i64 = (long long)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlock) {
+        const int idx = static_cast<int>(i64);
         const int x = idx % W, y = (idx / W) % H, ch = idx / (H * W);
         T acc = T(0);
         const int bin_lo = ch == 0 ? 0 : 1;

@@ -55,7 +55,14 @@ def _p(a: np.ndarray):
 
 
 def set_threads(n: int) -> None:
+    """Number of OpenMP threads of the following calls.  The environment variable only counts before
+    libgomp's first parallel region, so the runtime of the already-loaded library is told as well."""
     os.environ["OMP_NUM_THREADS"] = str(n)
+    lib()                                              # maps libgomp (DT_NEEDED of the oracle)
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:                                    # pragma: no cover
+        pass
 
 
 def corr_fwd(fm0, fm1, d, s):

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""CPU stand-in for bench.py's device layer -- TEST HARNESS, launched by tests/test_sharding_gloo.py as
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port P tests/bench_stub_main.py --gpus 2 --steps K --warmup W
+
+It runs bench.run() -- the real rank skeleton: WORLD_SIZE check, process-group init, setup, warmup,
+barrier, K timed steps, barrier, MAX over ranks, one JSON line on rank 0, teardown -- with the two
+op calls replaced by a sleep whose length depends on the rank, and gloo instead of RCCL.  The HIP
+library is not loaded; nothing here is reachable from bench.py itself.
+"""
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+
+class CpuStub:
+    backend = "gloo"
+    FWD_S, BWD_S = 0.002, 0.003
+
+    def __init__(self):
+        self.rank = bench.rank_env()[0]
+        self.calls = {"fwd": 0, "bwd": 0}
+
+    def init_process_group(self):
+        import torch.distributed as dist
+        dist.init_process_group(self.backend)
+
+    def setup(self, cfg, n_sets, seed):
+        assert seed == self.rank
+        self.n_sets = n_sets
+
+    def fwd(self, i):
+        assert 0 <= i < self.n_sets
+        self.calls["fwd"] += 1
+        time.sleep(self.FWD_S * (1 + self.rank))               # rank 1 is the slow shard
+
+    def bwd(self, i):
+        assert 0 <= i < self.n_sets
+        self.calls["bwd"] += 1
+        time.sleep(self.BWD_S * (1 + self.rank))
+
+    def synchronize(self):
+        pass
+
+    def new_event(self):
+        return [0.0]
+
+    def record(self, ev):
+        ev[0] = time.perf_counter()
+
+    def elapsed_ms(self, e0, e1):
+        return (e1[0] - e0[0]) * 1e3
+
+    def reduce_device(self):
+        return None
+
+
+if __name__ == "__main__":
+    a = bench.parse_args()
+    a.no_cpu_baseline = True
+    stub = CpuStub()
+    bench.run(a, stub)
+    n = stub.n_sets + a.warmup + a.steps
+    assert stub.calls == {"fwd": n, "bwd": n}, stub.calls
+    print(f"stub rank {stub.rank} done", file=sys.stderr)

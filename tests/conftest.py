@@ -26,7 +26,8 @@ def pytest_configure(config):
 
 
 def golden_files(prefix):
-    return sorted(GOLDEN.glob(f"{prefix}_*.npz"))
+    """Full-tensor fixtures of one op (the *_subsample fixtures have their own schema and test)."""
+    return sorted(f for f in GOLDEN.glob(f"{prefix}_*.npz") if not f.stem.endswith("_subsample"))
 
 
 def golden_ids(prefix):
@@ -70,4 +71,12 @@ ADVERSARIAL_ROIS = [
     [0.5, 0.5, 0.5, 0.5], [0.1, 0.1, 0.2, 0.3], [0.95, 0.9, 0.3, 0.4], [0.5, 0.5, 1.0, 1.0],
     [0.5, 0.5, 2.0, 2.0], [0.3, 0.7, 0.0, 0.0], [1.5, 1.5, 0.2, 0.2], [-0.5, -0.5, 0.2, 0.2],
     [0.25, 0.75, 0.01, 0.9], [0.5, 0.5, 0.123, 0.987], [3.0, 3.0, 0.5, 0.5],
+]
+
+# RoIs of negative height / width: their bins run in reverse order and one-pixel
+# bins stay non-empty in the reference (roipool_cuda.cu:41-50), so forward values are finite and
+# the backward deposits gradient.
+NEGATIVE_ROIS = [
+    [0.5, 0.5, -0.1, 0.4], [0.5, 0.5, 0.3, -0.2], [0.4, 0.6, -0.3, -0.3], [0.2, 0.8, -0.05, 0.5],
+    [0.7, 0.3, 0.6, -0.01], [0.5, 0.5, -1.5, 0.5],
 ]

@@ -68,3 +68,20 @@ def test_psroipool_known_answer(oracle):
     out = oracle.psroipool_fwd(fm, np.asarray([[3.0, 3.0, 0.5, 0.5]], np.float32), 2, 7)
     np.testing.assert_array_equal(out, g["out"])
     assert not out.any()
+
+
+def test_oracle_headline_subsample(oracle):
+    """The oracle at BASELINE.json's metric shape against the reference's values (seeded subsample)."""
+    from conftest import GOLDEN
+    path = GOLDEN / "corr_headline_subsample.npz"
+    g = load_golden(path)
+    B, C, H, W, d = (int(g[k]) for k in ("B", "C", "H", "W", "d"))
+    rng = np.random.default_rng(int(g["seed"]))
+    fm0, fm1 = rng.random((B, C, H, W), dtype=np.float32), rng.random((B, C, H, W), dtype=np.float32)
+    gout = rng.random((B, H, W, 2 * d + 1, 2 * d + 1), dtype=np.float32)
+    assert fm0.flat[12345] == g["fm0_probe"] and gout.flat[54321] == g["gout_probe"]
+    out = oracle.corr_fwd(fm0, fm1, d, 1).ravel()
+    np.testing.assert_array_equal(out[g["out_idx"]], g["out_val"])
+    g0, g1 = oracle.corr_bwd(gout, fm0, fm1, d, 1)
+    np.testing.assert_array_equal(g0.ravel()[g["g_idx"]], g["g0_val"])          # thread-owned order
+    np.testing.assert_allclose(g1.ravel()[g["g_idx"]], g["g1_val"], rtol=1e-5, atol=1e-5)

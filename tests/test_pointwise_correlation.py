@@ -16,11 +16,12 @@ import pytest
 import torch
 from torch.autograd import gradcheck
 
-from conftest import golden_files, golden_ids, load_golden
+from conftest import GOLDEN, golden_files, golden_ids, load_golden
 
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+GOLDEN_HEADLINE = GOLDEN / "corr_headline_subsample.npz"
 
 
 def _t(a):
@@ -70,7 +71,9 @@ CASES = [  # (B, C, H, W, d, s)
     (2, 5, 7, 9, 1, 1), (1, 3, 4, 5, 0, 1), (1, 8, 5, 3, 4, 1), (1, 7, 9, 9, 2, 5),
     (2, 64, 19, 23, 8, 1), (1, 256, 38, 63, 8, 1), (1, 96, 38, 75, 8, 1), (3, 33, 17, 31, 8, 1),
     (1, 4, 40, 70, 8, 1), (2, 128, 8, 8, 8, 1),
-    # one case per tuned forward kernel: 2-tile segments, 5-tile segments off the headline shape, 1-tile
+    # small-grid forward kernels (k_corr_fwd_segx): 2-tile segments (B*tiles_j*ceil(tiles_i/2) >= 160:
+    # the first two cases) and 1-tile segments.  The full-grid kernel (>= 192 five-tile segments) is
+    # compared at the headline shape itself, see test_matches_live_reference / test_headline_golden.
     (2, 48, 38, 63, 8, 1), (3, 20, 38, 75, 8, 1), (1, 70, 38, 75, 8, 1),
 ]
 
@@ -100,7 +103,10 @@ def test_matches_oracle(case, dtype, impl, oracle):
 
 @pytest.mark.parametrize("impl", [0, 1], ids=["auto", "generic"])
 @pytest.mark.parametrize("case", [(1, 256, 38, 63, 8, 1), (2, 512, 38, 75, 8, 1), (1, 40, 13, 29, 8, 1),
-                                  (2, 2, 10, 10, 3, 1), (1, 260, 21, 18, 8, 1)], ids=str)
+                                  (2, 2, 10, 10, 3, 1), (1, 260, 21, 18, 8, 1),
+                                  # BASELINE.json's metric shape and a second >= 192-segment grid: the
+                                  # full-grid forward kernel and the 16-wave backward, all 5.5 M cells
+                                  (8, 256, 38, 63, 8, 1), (6, 64, 38, 75, 8, 1), (8, 17, 38, 63, 8, 1)], ids=str)
 def test_matches_live_reference(case, impl, ref_modules):
     """HIP kernels vs the reference's own kernels on the same GPU, same inputs."""
     from detect_to_track.models import _ext
@@ -117,6 +123,58 @@ def test_matches_live_reference(case, impl, ref_modules):
     r0, r1 = ref_corr.pointwise_correlation_backward(gout, fm0, fm1, d, s)
     torch.testing.assert_close(g0, r0, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(g1, r1, rtol=1e-5, atol=1e-5)
+
+
+def test_headline_golden():
+    """B=8 C=256 38x63 d=8 against values the REFERENCE's kernels produced for the same seeded inputs
+    (tests/golden/corr_headline_subsample.npz: a seeded subsample of cells and gradient elements,
+    written by tests/golden/make_golden.py on an MI355X).  Needs no oracle/_ref at test time."""
+    from detect_to_track.models import _ext
+    g = load_golden(GOLDEN_HEADLINE)
+    B, C, H, W, d = (int(g[k]) for k in ("B", "C", "H", "W", "d"))
+    rng = np.random.default_rng(int(g["seed"]))
+    fm0, fm1 = rng.random((B, C, H, W), dtype=np.float32), rng.random((B, C, H, W), dtype=np.float32)
+    gout = rng.random((B, H, W, 2 * d + 1, 2 * d + 1), dtype=np.float32)
+    assert fm0.flat[12345] == g["fm0_probe"] and gout.flat[54321] == g["gout_probe"]   # same generator
+    for impl in (0, 2):
+        out = _n(_ext.pointwise_correlation_forward(_t(fm0), _t(fm1), d, 1, impl)).ravel()
+        np.testing.assert_array_equal(out[g["out_idx"]], g["out_val"])                 # bit-exact
+        g0, g1 = _ext.pointwise_correlation_backward(_t(gout), _t(fm0), _t(fm1), d, 1, impl)
+        np.testing.assert_allclose(_n(g0).ravel()[g["g_idx"]], g["g0_val"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(_n(g1).ravel()[g["g_idx"]], g["g1_val"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("impl", [0, 1], ids=["auto", "generic"])
+@pytest.mark.parametrize("case", [(4, 256, 20, 63, 8), (1, 64, 38, 63, 8), (2, 40, 13, 29, 8)], ids=str)
+def test_nonfinite_inputs_match_live_reference(case, impl, ref_modules):
+    """Inf / NaN in the feature maps and in gradOut: the set of non-finite output elements and every
+    finite value must be the reference's.  (The MFMA kernels multiply foreign window slots by 0; a
+    wave that sees a non-finite result recomputes its region in the reference's form.)"""
+    from detect_to_track.models import _ext
+    ref_corr = ref_modules[0]
+    B, C, H, W, d = case
+    torch.manual_seed(99)
+    fm0 = torch.rand(B, C, H, W, device=DEV)
+    fm1 = torch.rand(B, C, H, W, device=DEV)
+    gout = torch.rand(B, H, W, 2 * d + 1, 2 * d + 1, device=DEV)
+    fm1[0, 3, 5, 7] = float("inf")
+    fm1[B - 1, C - 1, H - 1, W - 2] = float("nan")
+    fm0[0, 5, 2, 11] = float("-inf")
+    fm0[B - 1, 0, 9, 20] = float("nan")
+    gout[0, 6, 6, 3, 4] = float("inf")
+    gout[0, 7, 9, 16, 16] = float("nan")          # a cell the reference never reads (+d column)
+    out = _ext.pointwise_correlation_forward(fm0, fm1, d, 1, impl)
+    ref = ref_corr.pointwise_correlation_forward(fm0, fm1, d, 1)
+    assert torch.equal(torch.isfinite(out), torch.isfinite(ref))
+    assert torch.equal(torch.nan_to_num(out, 0., 0., 0.), torch.nan_to_num(ref, 0., 0., 0.))
+    g0, g1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, d, 1, impl)
+    r0, r1 = ref_corr.pointwise_correlation_backward(gout, fm0, fm1, d, 1)
+    for got, want in ((g0, r0), (g1, r1)):
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        assert torch.equal(torch.isposinf(got), torch.isposinf(want))
+        assert torch.equal(torch.isneginf(got), torch.isneginf(want))
+        torch.testing.assert_close(torch.nan_to_num(got, 0., 0., 0.), torch.nan_to_num(want, 0., 0., 0.),
+                                   rtol=1e-5, atol=1e-5)
 
 
 def test_north_star_shape_properties():

@@ -13,7 +13,7 @@ import pytest
 import torch
 from torch.autograd import gradcheck
 
-from conftest import ADVERSARIAL_ROIS, golden_files, golden_ids, load_golden, random_rois
+from conftest import ADVERSARIAL_ROIS, NEGATIVE_ROIS, golden_files, golden_ids, load_golden, random_rois
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -102,6 +102,29 @@ def test_matches_live_reference(case, ref_modules):
     assert bool(((out == ref) | (out.isnan() & ref.isnan())).all())       # bit-exact
     gin = _ext.roipool_backward(gout, rois, H, W)
     torch.testing.assert_close(gin, ref_roi.roipool_backward(gout, rois, H, W), **TOL32)
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2], ids=["auto", "generic", "tuned"])
+@pytest.mark.parametrize("shape", [(3, 20, 30, 7), (70, 38, 63, 7), (2, 9, 14, 3)], ids=str)
+def test_negative_extent_rois(shape, impl, oracle, ref_modules):
+    """RoIs of negative height / width against the oracle AND the reference's kernels."""
+    from detect_to_track.models import _ext
+    C, H, W, k = shape
+    rng = np.random.default_rng(C * 100 + k)
+    rois = np.asarray(NEGATIVE_ROIS + ADVERSARIAL_ROIS[:3], np.float32)
+    fm = rng.random((C, H, W), dtype=np.float32)
+    gout = rng.random((len(rois), C, k, k), dtype=np.float32)
+    want = oracle.roipool_fwd(fm, rois, k)
+    out = _n(_ext.roipool_forward(_t(fm), _t(rois), k, impl))
+    np.testing.assert_array_equal(np.isnan(out), np.isnan(want))
+    np.testing.assert_allclose(np.nan_to_num(out), np.nan_to_num(want), **TOL32)
+    want_g = oracle.roipool_bwd(gout, rois, H, W)
+    assert want_g.sum() > 0                                      # these RoIs do deposit gradient
+    gin = _n(_ext.roipool_backward(_t(gout), _t(rois), H, W, impl))
+    np.testing.assert_allclose(gin, want_g, **TOL32)
+    ref = _n(ref_modules[1].roipool_backward(_t(gout), _t(rois), H, W))
+    np.testing.assert_allclose(gin, ref, **TOL32)
+    np.testing.assert_array_equal(_n(_ext.roipool_bins(_t(rois), H, W, k)), oracle.roipool_bins(rois, H, W, k))
 
 
 def test_config3_properties():

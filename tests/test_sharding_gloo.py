@@ -5,8 +5,10 @@ depend only on its own shard.  The only cross-rank operations in bench.py are th
 and the MAX-over-ranks reduction; both are exercised here over gloo, together with the
 shard-independence property itself (checked with the CPU oracle: test infrastructure).
 """
+import json
 import os
 import socket
+import subprocess
 import sys
 from pathlib import Path
 
@@ -76,3 +78,40 @@ def test_corr_counts_match_baseline_md():
     c = bench.corr_counts(**bench.WORKLOADS["corr_B8_C256_38x63_d8"])
     assert c["vox"] == 5534928 and c["fwd_bytes"] == 61363008 and c["bwd_bytes"] == 100586304
     assert c["fwd_flops"] == 2103443456 and c["bwd_flops"] == 2 * 2103443456
+
+
+@pytest.mark.timeout(300)
+def test_bench_rank_skeleton_under_torchrun():
+    """bench.run() end to end under `torch.distributed.run --nproc-per-node 2` exactly as the driver
+    launches bench.py for N > 1 (rendezvous on 127.0.0.1), with the device layer replaced BY THIS
+    TEST's harness (tests/bench_stub_main.py: gloo, op calls = rank-dependent sleeps)."""
+    K, W = 4, 2
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(ROOT / "tests" / "bench_stub_main.py"), "--gpus", "2", "--steps", str(K), "--warmup", str(W)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                        # rank 0 prints ONE line, rank 1 none
+    d = json.loads(lines[0])
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert d["metric"] == bench.METRIC and d["n_gpus"] == 2 and d["steps"] == K and d["warmup"] == W
+    assert d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "shard2"
+    # the slow rank (rank 1 sleeps 2x) sets the time: MAX over ranks, not rank 0's own clock
+    assert d["ms_per_step"] >= 2 * (2 + 3) * 0.95, d["ms_per_step"]
+    vox = bench.corr_counts(**bench.WORKLOADS["corr_B8_C256_38x63_d8"])["vox"]
+    assert abs(d["value"] - 2 * vox / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d                          # rank 0 at N = 1 only
+    assert p.stderr.count("stub rank") == 2
+
+
+def test_bench_single_rank_refuses_mismatched_world():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    a = bench.parse_args(["--gpus", "2"])
+    with pytest.raises(SystemExit):
+        bench.run(a, object())                              # WORLD_SIZE is 1 here: refused before any device call

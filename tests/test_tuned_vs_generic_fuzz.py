@@ -28,6 +28,8 @@ def _rois(rng, R):
     s[kind == 1] = rng.uniform(1.0, 2.5, (int((kind == 1).sum()), 2))       # larger than the map
     c[kind == 2] = rng.uniform(-0.5, 1.5, (int((kind == 2).sum()), 2))      # centre off the map
     s[kind == 3, 0] = 0.01                                                  # a sliver
+    s[kind == 4] *= -1.0                                                    # negative height and width
+    s[kind == 5, 1] *= -0.3                                                 # negative width only
     return torch.from_numpy(np.concatenate([c, s], 1).astype(np.float32)).to(DEV)
 
 
