@@ -17,7 +17,7 @@
 //
 // Forward kernels (all bit-identical): workgroups own SEGMENTS of vertically stacked p-tiles and
 // copy the union of their windows into LDS by LDS-DMA, 16 channels at a time --
-//   k_corr_fwd_seg        5 tiles / 15 waves, two staged chunks   (grids >= 192 segments: B = 8)
+//   k_corr_fwd_seg        5 tiles / 15 waves, ring of 3 chunks    (grids >= 192 segments: B = 8)
 //   k_corr_fwd_segx<2,4>  2 tiles /  6 waves, ring of 4 chunks    (medium grids)
 //   k_corr_fwd_segx<1,4>  1 tile  /  3 waves, ring of 4 chunks    (the real model's B = 1 pairs)
 // The epilogue stages the segment's outputs (including the structural zeros the reference gets
@@ -34,6 +34,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load, dword aligned
 
 #define D2T_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// In-kernel stamps for the developer harness csrc/lab/fwd_lab.hip (a separate diagnostic build, see
+// the MI355X guide "In-kernel stamps").  The product library is built without D2T_LAB: no stamp
+// executes there.
+#ifdef D2T_LAB
+__device__ unsigned long long* lab_stamps;                          // [workgroup][32]
+#define D2T_STAMP(i)                                                                                  \
+    do {                                                                                              \
+        if (threadIdx.x == 0) {                                                                       \
+            unsigned long long t_;                                                                    \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            lab_stamps[blockIdx.x * 32 + (i)] = t_;                                                   \
+        }                                                                                             \
+    } while (0)
+#define D2T_STAMP_RT(i)                                                                               \
+    do {                                                                                              \
+        if (threadIdx.x == 0) {                                                                       \
+            unsigned long long t_;                                                                    \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            lab_stamps[blockIdx.x * 32 + (i)] = t_;                                                   \
+        }                                                                                             \
+    } while (0)
+#else
+#define D2T_STAMP(i)
+#define D2T_STAMP_RT(i)
+#endif
 
 constexpr int TP = 4;                      // p-tile edge: 4x4 pixels = MFMA M = 16
 constexpr int DT = 8;                      // d_max the tuned kernels are built for
@@ -63,8 +89,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // one per CU.  Arithmetic is unchanged (ascending-channel MFMA chain): bit-identical results.
 // ------------------------------------------------------------------------------------
 constexpr int SG_NU = 5;                            // p-tiles per segment
-constexpr int SG_NU1 = 5;                           // tiles of the first pass (5 = single pass)
-constexpr int SG_WAVES = 15;                        // 30 (tile, tile-group) tasks, two per wave
+constexpr int SG_WAVES = 15;                        // <= 30 (tile, tile-group) tasks, at most two per wave
 constexpr int SG_THREADS = SG_WAVES * 64;
 constexpr int SG_KC = 16;                           // channels per staged chunk (4 k-steps)
 constexpr int SG_ROWS = 4 * SG_NU + 2 * DT - 1;     // 35 window rows of a segment
@@ -72,27 +97,58 @@ constexpr int SG_SLOTS = SG_ROWS * NCG + 1;         // 176 slots of 16 bytes per
 constexpr int SG_BPL = SG_SLOTS * 4;                // 704 floats: plane stride = 0 mod 64 dwords -> the four
                                                     // k-slot lane groups of a ds_read_b128 hit disjoint banks
 constexpr int SG_APL = SG_NU * 16;                  // 80 floats: FM0 pixels of one channel
-constexpr int SG_BUF = SG_KC * (SG_BPL + SG_APL);   // floats per buffer (48.75 KB)
-constexpr int SG_STAGE = SG_NU * 16 * CELLS;        // out staging (90.3 KB), aliases the buffers
-constexpr int SG_LDS = 2 * SG_BUF > SG_STAGE ? 2 * SG_BUF : SG_STAGE;
+constexpr int SG_BUF = SG_KC * (SG_BPL + SG_APL);   // floats per buffer (49 KB)
+constexpr int SG_RING = 3;                          // staged chunks: one being read, one landed, one in flight
+constexpr int SG_DUMMY = 256;                       // floats: where parked DMA instructions land
+constexpr int SG_STAGE = SG_NU * 16 * CELLS;        // out staging (90.3 KB), aliases the ring
+constexpr int SG_LDS = SG_RING * SG_BUF + SG_DUMMY > SG_STAGE ? SG_RING * SG_BUF + SG_DUMMY : SG_STAGE;
+static_assert(SG_LDS * 4 <= 160 * 1024, "LDS budget");
 
-constexpr int SG_NPB = SG_KC * SG_SLOTS;            // 2816 FM1 slots (16 bytes) per chunk = 44 wave-instructions
-constexpr int SG_NPA = SG_KC * 4 * SG_NU;           // 320 FM0 pieces per chunk
-constexpr int SG_BI = (SG_NPB + 63) / 64;           // 44 wave-instructions move the FM1 region of a chunk
-constexpr int SG_BIW = (SG_BI + SG_WAVES - 1) / SG_WAVES;   // 3 per wave
+constexpr int SG_AI = SG_KC * 4 * SG_NU / 64;       // 5 DMA wave-instructions move the FM0 pixels of a chunk
+constexpr int SG_MAXDMA = (SG_KC * SG_SLOTS / 64 + SG_AI + SG_WAVES - 1) / SG_WAVES;   // 4: most a wave issues per chunk
+static_assert(SG_KC * 4 * SG_NU % 64 == 0 && SG_MAXDMA <= SG_KC / 4, "DMA plan");
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+template <int N>
+__device__ __forceinline__ void dma_wait_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// The kernel.  Per chunk of 16 channels a wave issues its 2-3 LDS-DMA instructions of chunk ch+2, 4
+// fragment fetches and 4 x NT x 4 MFMAs; the fragments of k-step ks+1 are fetched under the MFMAs of
+// k-step ks -- across the chunk boundary too, which is what the third ring slot buys: chunk ch+1 has
+// landed and is published by the barrier that sits BEHIND k-step 2 of chunk ch, so the matrix pipe
+// never waits for an LDS round trip and a chunk's DMA has more than a chunk time to land.  LDS-DMA
+// loads retire in order and a wave issues the same number (nd) for every chunk, so `vmcnt(nd)` at that
+// barrier means "my part of chunk ch+1 has landed" (chunk ch+2's may be in flight).
+//
+// DMA instructions are the expensive part of the loop (measured with csrc/lab/fwd_lab: removing them
+// takes 12 k cycles off a 67 k-cycle loop, ~50 cycles of SIMD issue each), so there are as few as the
+// bytes allow: the image pitch is the segment's own row count (27 rows at 38-row maps, not the
+// 35-row maximum), instructions are dealt round-robin to the waves, none is a parked dummy.
+//
+// Work distribution.  The segment's ACTIVE tile-groups (a tile at the top or bottom of the map has
+// fewer window rows, hence fewer than 6) are numbered consecutively and dealt round-robin: task q
+// goes to wave q mod 15.  A workgroup's waves are placed on the CU's four SIMDs cyclically (checked
+// with HW_REG_HW_ID), so this also balances the matrix pipes: at 38 rows every segment has 27 tasks
+// -> 7 / 7 / 7 / 6 per SIMD.  (The first version gave wave w the fixed slots w and w+15 of a 5 x 6
+// table and issued the MFMAs of empty slots as well: 8 per SIMD.)
 __global__ void __launch_bounds__(SG_THREADS)
 k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
                int C, int H, int W, int tiles_i, int tiles_j, int nseg)
 {
     __shared__ __attribute__((aligned(16))) float smem[SG_LDS];
 
+    D2T_STAMP(0); D2T_STAMP_RT(8);
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef D2T_LAB
+    if (lane == 0) { unsigned hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); lab_stamps[blockIdx.x * 32 + 16 + wave] = hw_; }
+#endif
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
-    const int useg0 = seg * SG_NU, nuseg = tiles_i - useg0 < SG_NU ? tiles_i - useg0 : SG_NU;
+    const int u0 = seg * SG_NU, nu = tiles_i - u0 < SG_NU ? tiles_i - u0 : SG_NU;
     const int j0 = tj * TP, HW = H * W;
     const unsigned plane_bytes = (unsigned)C * HW * 4u;
     const __amdgpu_buffer_rsrc_t r1 =
@@ -102,14 +158,6 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
     const __amdgpu_buffer_rsrc_t ro =
         __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * HW * CELLS, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
 
-  // The segment is processed in two passes (3 tiles, then the rest): the first pass's outputs are
-  // stored WRITE-THROUGH (sc1) and drain to HBM while the second pass computes, so that only the
-  // second pass's stores (40 % of the segment) are left for the unoverlapped tail of the kernel --
-  // with one workgroup per CU every workgroup reaches its epilogue at the same moment.
-  for (int pass = 0; pass < 2; ++pass) {
-    const int u0 = useg0 + (pass ? SG_NU1 : 0);
-    const int nu = pass ? nuseg - SG_NU1 : (nuseg < SG_NU1 ? nuseg : SG_NU1);
-    if (nu <= 0) break;
     const int R0 = 4 * u0 - DT > 0 ? 4 * u0 - DT : 0;                // region rows [R0, R1) inside the map
     const int R1 = 4 * (u0 + nu) + DT - 1 < H ? 4 * (u0 + nu) + DT - 1 : H;
     const int nrows = R1 - R0;
@@ -117,73 +165,103 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
 
     // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction copies 64 pieces of
     // 16 bytes from per-lane global addresses into 64 CONSECUTIVE 16-byte LDS slots, no VGPR round
-    // trip.  The LDS image is [channel][row][column group] with a fixed 35-row pitch, so piece e
-    // lands in slot e.  The buffer descriptor covers exactly this batch item's C planes: a piece of a
-    // channel >= C (last chunk) is out of range and arrives as exact zeros.  Columns outside the
-    // map read whatever neighbours them in memory: MFMA columns are independent and those cells are
-    // masked in the epilogue.  Pieces of rows the segment does not have are parked out of range.
+    // trip.  The LDS image of a chunk is [channel][row][column group] with a pitch of P slots per
+    // channel (the segment's rows x 5, rounded up to 16 slots so that the plane stride stays 0 mod 64
+    // dwords: the four k-slot lane groups of a ds_read_b128 hit disjoint banks), followed by the FM0
+    // pixels [channel][20 pixel rows]; piece e of either part lands in slot e.  The buffer descriptor
+    // covers exactly this batch item's C planes: a piece of a channel >= C (last chunk, and the two
+    // chunks staged past the end) is out of range and arrives as exact zeros without touching memory.
+    // Columns outside the map read whatever neighbours them in memory: MFMA columns are independent
+    // and those cells are masked in the epilogue.  Pad slots and pixel rows past the map are parked
+    // out of range.  Instruction y of a chunk (FM1 instructions first, then the 5 FM0 ones) belongs to
+    // wave y mod 15.
     constexpr int OOR = 0x7ffffff0;                                  // parked byte offset: always out of range
-    int pb_voff[SG_BIW];
-    bool pb_on[SG_BIW];
+    const int P = (nrows * NCG + 15) & ~15;                          // slots per channel
+    const int BPL = 4 * P;                                           // floats per channel plane
+    const int a_base = SG_KC * BPL;                                  // float offset of the FM0 part in a buffer
+    const int nBI = P >> 2;                                          // FM1 instructions per chunk (16 * P / 64)
+    const int ndma = nBI + SG_AI;
+    const int nd = (ndma - wave + SG_WAVES - 1) / SG_WAVES;          // this wave's instructions per chunk (wave-uniform)
+    const float rP = 1.0f / (float)P;
+    int dv[SG_MAXDMA], dl[SG_MAXDMA];                                // byte offset in the planes / float offset in the buffer
+    bool dA[SG_MAXDMA];
 #pragma unroll
-    for (int k = 0; k < SG_BIW; ++k) {
-        const int e = (wave + SG_WAVES * k) * 64 + lane;
-        const int ch = e / SG_SLOTS, rem = e - ch * SG_SLOTS;        // slot rem of channel ch (slot 175: pad)
-        const int row = rem / NCG, cg = rem - row * NCG;
-        pb_on[k] = e < SG_NPB;
-        pb_voff[k] = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 : OOR;
-    }
-    int pa_voff = OOR;
-    const bool pa_on = wave < (SG_NPA + 63) / 64;
-    {
-        const int e = wave * 64 + lane;                              // FM0 piece: (channel, pixel row of the segment)
-        const int ch = e / (4 * SG_NU), prow = e - ch * (4 * SG_NU);
-        const int i = 4 * u0 + prow;
-        if (pa_on && e < SG_NPA && i < H) pa_voff = (ch * HW + i * W + j0) * 4;
+    for (int k = 0; k < SG_MAXDMA; ++k) {
+        const int y = wave + SG_WAVES * k;
+        dA[k] = y >= nBI;                                            // wave-uniform
+        if (!dA[k]) {
+            const int e = y * 64 + lane;
+            const int ch = (int)(((float)e + 0.5f) * rP), rem = e - ch * P;   // e / P, exact for e < 2^15
+            const int row = rem / NCG, cg = rem - row * NCG;
+            dv[k] = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 : OOR;
+            dl[k] = y * 256;
+        } else {
+            const int e = (y - nBI) * 64 + lane;                     // FM0 piece: (channel, pixel row of the segment)
+            const int ch = e / (4 * SG_NU), prow = e - ch * (4 * SG_NU);
+            const int i = 4 * u0 + prow;
+            dv[k] = i < H ? (ch * HW + i * W + j0) * 4 : OOR;
+            dl[k] = a_base + (y - nBI) * 256;
+        }
     }
     const int chunk_bytes = SG_KC * HW * 4;
-    auto stage = [&](float* buf, int chunk) {
-        const int cb = chunk * chunk_bytes;
-#pragma unroll
-        for (int k = 0; k < SG_BIW; ++k) {
-            if (pb_on[k]) {
-                const int v = pb_voff[k] == OOR ? OOR : pb_voff[k] + cb;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(buf + (wave + SG_WAVES * k) * 256), 16, v, 0, 0, 0);
-            }
-        }
-        if (pa_on) {
-            const int v = pa_voff == OOR ? OOR : pa_voff + cb;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)(buf + SG_KC * SG_BPL + wave * 256), 16, v, 0, 0, 0);
-        }
+    auto dma = [&](int slot, int chunk, auto k_c) {                  // this wave's k-th DMA instruction of `chunk` into ring slot `slot`
+        constexpr int k = decltype(k_c)::value;
+        if (k >= nd) return;                                         // wave-uniform
+        const int v = dv[k] == OOR ? OOR : dv[k] + chunk * chunk_bytes;
+        float* dst = smem + slot * SG_BUF + dl[k];
+        if (dA[k]) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)dst, 16, v, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, v, 0, 0, 0);
     };
+    // "my instructions of the previous chunk have landed" (nd younger ones may be in flight) + barrier
+    auto wait_prev_chunk_and_barrier = [&]() {
+        if (nd >= 4) dma_wait_barrier<4>();
+        else if (nd == 3) dma_wait_barrier<3>();
+        else if (nd == 2) dma_wait_barrier<2>();
+        else if (nd == 1) dma_wait_barrier<1>();
+        else dma_wait_barrier<0>();
+    };
+    using std::integral_constant;
+    typedef integral_constant<int, 0> K0; typedef integral_constant<int, 1> K1;
+    typedef integral_constant<int, 2> K2; typedef integral_constant<int, 3> K3;
+    // chunk 0 goes out before anything else is computed; chunk 1 behind the task tables (every workgroup
+    // of the chip starts at the same moment: chunk 0 alone lands sooner than both together)
+    dma(0, 0, K0{}); dma(0, 0, K1{}); dma(0, 0, K2{}); dma(0, 0, K3{});
+    D2T_STAMP(10);
 
-    // ---- this wave's two tasks: id = tile*6 + tile-group
-    int t_tile[2], t_off[2], t_ng[2];
+    // ---- this wave's tasks: active tile-groups in (tile, tile-group) order, task q -> wave q mod 15
+    int tgs[SG_NU];                                                  // tile-groups of tile t (0 past the segment)
+#pragma unroll
+    for (int t = 0; t < SG_NU; ++t) {
+        const int u = u0 + t;
+        const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;
+        const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
+        tgs[t] = t < nu && wb > wa ? ((wb - wa) * NCG + 15) >> 4 : 0;
+    }
+    int t_tile[2], t_T[2], t_ng[2];
     bool t_on[2];
+    int l_off[2], a_off[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int id = wave + SG_WAVES * k, t = id / 6, T = id - t * 6;
+        int q = wave + SG_WAVES * k, t = 0;
+#pragma unroll
+        for (int tt = 0; tt < SG_NU; ++tt)
+            if (t == tt && q >= tgs[tt]) { q -= tgs[tt]; ++t; }
+        t_on[k] = t < SG_NU;                                          // q < tgs[t]
+        t = t_on[k] ? t : 0;
+        const int T = t_on[k] ? q : 0;
         const int u = u0 + t;
         const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;              // tile's window rows inside the map
         const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
         const int ng = (wb - wa) * NCG;
-        t_tile[k] = t;
-        t_ng[k] = ng;
-        t_on[k] = t < nu && 16 * T < ng;
-        t_off[k] = ((wa - R0) * NCG + 16 * T) * 4;                   // float offset of the tile-group's first slot
-    }
-    // lane's slot inside the tile-group (clamped to the tile's last group; masked in the epilogue);
-    // a wave without a second task recomputes a valid slot into a dead accumulator: no branch
-    int l_off[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int T = (wave + SG_WAVES * k) % 6;
+        t_tile[k] = t; t_T[k] = T; t_ng[k] = ng;
+        // lane's slot inside the tile-group (clamped to the tile's last group; masked in the epilogue)
         int gi = 16 * T + n;
-        gi = gi < t_ng[k] ? gi : (t_ng[k] > 0 ? t_ng[k] - 1 : 0);
-        l_off[k] = t_on[k] ? t_off[k] - 16 * T * 4 + gi * 4 + g * SG_BPL : g * SG_BPL;
+        gi = gi < ng ? gi : (ng > 0 ? ng - 1 : 0);
+        l_off[k] = ((wa - R0) * NCG + gi) * 4 + g * BPL;
+        a_off[k] = a_base + g * SG_APL + t * 16 + n;
     }
-    const int a_off0 = SG_KC * SG_BPL + g * SG_APL + (t_on[0] ? t_tile[0] : 0) * 16 + n;
-    const int a_off1 = SG_KC * SG_BPL + g * SG_APL + (t_on[1] ? t_tile[1] : 0) * 16 + n;
+
+    dma(1, 1, K0{}); dma(1, 1, K1{}); dma(1, 1, K2{}); dma(1, 1, K3{});
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -192,71 +270,121 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
         for (int s = 0; s < 4; ++s) acc[k][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = (C + SG_KC - 1) / SG_KC;
-    stage(smem, 0);
-    __syncthreads();                                                 // vmcnt(0) + barrier: chunk 0 has landed
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* cur = smem + (ch & 1) * SG_BUF;
-        stage(smem + ((ch + 1) & 1) * SG_BUF, ch + 1);               // lands during this chunk's MFMAs (past the end: zeros)
-        if (t_on[1]) {                                               // wave-uniform: two tasks (t_on[1] implies t_on[0])
+#ifdef D2T_LAB
+    unsigned long long lab_dma_wait = 0, lab_bar_wait = 0;
+    const bool LAB_WAVE0 = wave == 0;
+#endif
+    struct Frag { f32x4 q[2]; float a[2]; };
+    auto run = [&](auto nt_c) {
+        constexpr int NT = decltype(nt_c)::value;                    // tasks of this wave: 0, 1 or 2
+        auto fetch = [&](Frag& f, const float* buf, int ks) {
 #pragma unroll
-            for (int ks = 0; ks < SG_KC / 4; ++ks) {
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(cur + l_off[0] + ks * 4 * SG_BPL);
-                const f32x4 q1 = *reinterpret_cast<const f32x4*>(cur + l_off[1] + ks * 4 * SG_BPL);
-                const float a0 = cur[a_off0 + ks * 4 * SG_APL], a1 = cur[a_off1 + ks * 4 * SG_APL];
-                acc[0][0] = D2T_MFMA(a0, q0.x, acc[0][0]);
-                acc[1][0] = D2T_MFMA(a1, q1.x, acc[1][0]);
-                acc[0][1] = D2T_MFMA(a0, q0.y, acc[0][1]);
-                acc[1][1] = D2T_MFMA(a1, q1.y, acc[1][1]);
-                acc[0][2] = D2T_MFMA(a0, q0.z, acc[0][2]);
-                acc[1][2] = D2T_MFMA(a1, q1.z, acc[1][2]);
-                acc[0][3] = D2T_MFMA(a0, q0.w, acc[0][3]);
-                acc[1][3] = D2T_MFMA(a1, q1.w, acc[1][3]);
+            for (int k = 0; k < NT; ++k) {
+                f.q[k] = *reinterpret_cast<const f32x4*>(buf + l_off[k] + ks * 4 * BPL);
+                f.a[k] = buf[a_off[k] + ks * 4 * SG_APL];
             }
-        } else if (t_on[0]) {                                        // one task
+        };
+        auto mfma = [&](const Frag& f, int s_lo, int s_hi) {
 #pragma unroll
-            for (int ks = 0; ks < SG_KC / 4; ++ks) {
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(cur + l_off[0] + ks * 4 * SG_BPL);
-                const float a0 = cur[a_off0 + ks * 4 * SG_APL];
-                acc[0][0] = D2T_MFMA(a0, q0.x, acc[0][0]);
-                acc[0][1] = D2T_MFMA(a0, q0.y, acc[0][1]);
-                acc[0][2] = D2T_MFMA(a0, q0.z, acc[0][2]);
-                acc[0][3] = D2T_MFMA(a0, q0.w, acc[0][3]);
-            }
+            for (int s = s_lo; s < s_hi; ++s)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) acc[k][s] = D2T_MFMA(f.a[k], f.q[k][s], acc[k][s]);
+        };
+        Frag f0, f1;
+        D2T_STAMP(11);
+#ifdef D2T_LAB
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        D2T_STAMP(12);
+#endif
+        wait_prev_chunk_and_barrier();                               // chunk 0 has landed (chunk 1 may be in flight)
+        D2T_STAMP(1);
+        fetch(f0, smem, 0);
+        int s_cur = 0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int s_nxt = s_cur == SG_RING - 1 ? 0 : s_cur + 1;  // chunk ch+1
+            const int s_fre = s_nxt == SG_RING - 1 ? 0 : s_nxt + 1;  // chunk ch-1: every wave has passed the barrier
+            const float* cur = smem + s_cur * SG_BUF;                // behind its last read of that slot
+            // sched_barrier: the fetch of the NEXT k-step is issued before this k-step's MFMAs (hipcc
+            // otherwise sinks it behind them and waits for the LDS round trip in front of every k-step);
+            // a DMA instruction goes behind the MFMAs of a k-step.  Behind the barrier every wave of a
+            // SIMD is released at once: each first issues MFMAs it already holds the operands of.
+#define D2T_PIN() __builtin_amdgcn_sched_barrier(0)
+            fetch(f1, cur, 1); D2T_PIN(); mfma(f0, 0, 4); dma(s_fre, ch + 2, K0{}); D2T_PIN();
+            fetch(f0, cur, 2); D2T_PIN(); mfma(f1, 0, 4); dma(s_fre, ch + 2, K1{}); dma(s_fre, ch + 2, K2{}); D2T_PIN();
+            fetch(f1, cur, 3); D2T_PIN(); mfma(f0, 0, 4); dma(s_fre, ch + 2, K3{}); D2T_PIN();
+#ifdef D2T_LAB
+            unsigned long long tb0_, tb1_, tb2_;
+            if (LAB_WAVE0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0_)::"memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (LAB_WAVE0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1_)::"memory");
+#endif
+            wait_prev_chunk_and_barrier();                           // my part of chunk ch+1 has landed; publish
+#ifdef D2T_LAB
+            if (LAB_WAVE0) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb2_)::"memory"); lab_dma_wait += tb1_ - tb0_; lab_bar_wait += tb2_ - tb1_; }
+#endif
+            mfma(f1, 0, 2); D2T_PIN();
+            fetch(f0, smem + s_nxt * SG_BUF, 0); D2T_PIN(); mfma(f1, 2, 4); D2T_PIN();
+#undef D2T_PIN
+            s_cur = s_nxt;
         }
-        __syncthreads();
-    }
+    };
+    if (t_on[1]) run(integral_constant<int, 2>{});                   // wave-uniform
+    else if (t_on[0]) run(integral_constant<int, 1>{});
+    else run(integral_constant<int, 0>{});
+    D2T_STAMP(2);
+#ifdef D2T_LAB
+    if (threadIdx.x == 0) { lab_stamps[blockIdx.x * 32 + 13] = lab_dma_wait; lab_stamps[blockIdx.x * 32 + 14] = lab_bar_wait; }
+#endif
+    __syncthreads();                                                 // vmcnt(0): the zero chunks staged past the end
+    D2T_STAMP(3);
 
     // ---- epilogue: [nu tiles][16 pixels][17][17] through LDS, then 4*nu contiguous runs ----
-    for (int e = tid; e < nu * 16 * CELLS; e += SG_THREADS) smem[e] = 0.f;
-    __syncthreads();
+    // A lane's 4 x 4 block covers, for pixel (g, r) and displaced row rho, the cells cj = 4cg + s - r;
+    // over the five column groups that is every cj in [0, 16], so the scatter itself writes the
+    // structural zeros (cj = 16, ci = 16, displaced column outside the map) of the rows it covers.
+    // Rows of the 17 x 17 map whose displaced row lies outside the tile's window (ci = 16 of the
+    // tile's last pixel row; rows cut off by the map edge) are zero-filled here.
+    for (int e = tid; e < nu * 16 * CW; e += SG_THREADS) {
+        const int p = e / CW, ci = e - p * CW, t = p >> 4, gg = (p >> 2) & 3;
+        const int u = u0 + t;
+        const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;
+        const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
+        const int rho = 4 * u + gg - DT + ci;
+        if (rho < wa || rho >= wb) {
+            float* row = smem + p * CELLS + ci * CW;
+#pragma unroll
+            for (int cj = 0; cj < CW; ++cj) row[cj] = 0.f;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int T = (wave + SG_WAVES * k) % 6;
-        const int gi = 16 * T + n;
+        const int gi = 16 * t_T[k] + n;
         if (t_on[k] && gi < t_ng[k]) {
             const int u = u0 + t_tile[k];
             const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;
             const int rho = wa + gi / NCG, cg = gi - (gi / NCG) * NCG;   // displaced row, column group
             const int ci = rho - (4 * u + g) + DT;                   // di - i + d, pixel row i = 4u + g
-            if (ci >= 0 && ci < 2 * DT) {
+            if (ci >= 0 && ci <= 2 * DT) {
                 float* row = smem + (t_tile[k] * 16 + 4 * g) * CELLS + ci * CW;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int dj = colL + 4 * cg + s;
+                    const bool live = ci < 2 * DT && dj >= 0 && dj < W;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int cj = dj - (j0 + r) + DT;
-                        if (cj >= 0 && cj < 2 * DT && dj >= 0 && dj < W) row[r * CELLS + cj] = acc[k][s][r];
+                        if (cj >= 0 && cj <= 2 * DT) row[r * CELLS + cj] = live && cj < 2 * DT ? acc[k][s][r] : 0.f;
                     }
                 }
             }
         }
     }
     __syncthreads();
+    D2T_STAMP(4);
     // 16-byte write-through stores (dword-aligned addresses): a pixel row of the strip is nj*289
     // contiguous floats in out and starts 16-byte aligned in the LDS image
     const int nj = W - j0 < TP ? W - j0 : TP;
-    const int run = nj * CELLS, run4 = run >> 2;                     // floats / whole float4s per pixel row
+    const int run_ = nj * CELLS, run4 = run_ >> 2;                   // floats / whole float4s per pixel row
     const int prs = (H - 4 * u0 < 4 * nu ? H - 4 * u0 : 4 * nu);     // pixel rows that exist
     for (int e = tid; e < prs * run4; e += SG_THREADS) {
         const int pr = e / run4, q = e - pr * run4;
@@ -265,13 +393,16 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
                                                ro, off, 0, 16);     // aux 16 = sc1 (write-through)
     }
-    const int tail = run - 4 * run4;                                 // 0..3 floats per pixel row (nj < 4)
+    const int tail = run_ - 4 * run4;                                // 0..3 floats per pixel row (nj < 4)
     for (int e = tid; e < prs * tail; e += SG_THREADS) {
         const int pr = e / tail, q = 4 * run4 + (e - pr * tail);
         out[((size_t)b * HW + (4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
     }
-    __syncthreads();                                                 // LDS image free before the next pass restages
-  }
+    D2T_STAMP(5);
+#ifdef D2T_LAB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the stores have been acknowledged
+    D2T_STAMP(6); D2T_STAMP_RT(9);
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -306,12 +437,6 @@ struct SegX {
     static_assert(INFLIGHT <= 63, "vmcnt is a 6-bit counter");
     static_assert(LDS * 4 <= 160 * 1024, "LDS budget");
 };
-
-template <int N>
-__device__ __forceinline__ void dma_wait_barrier()
-{
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 
 template <int NU, int RING>
 __global__ void __launch_bounds__(3 * NU * 64)
