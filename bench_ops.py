@@ -94,9 +94,11 @@ def main():
         rois = torch.from_numpy(random_rois(R, 1)).to(dev)
         nbw = L.d2t_psroipool_bwd_workspace_bytes(R, nT, H, W, k, 4)
         wb = _ws(nbw, dev)
+        nfw = L.d2t_psroipool_fwd_workspace_bytes(R, nT, H, W, k, 4)
+        wf = _ws(nfw, dev)
         nb = R * nT * k * k * 4 + C * H * W * 4 + R * 16
         emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "fwd", timed(lambda i: _check(L.d2t_psroipool_fwd_f32(
-            fm[i].data_ptr(), rois.data_ptr(), out[i].data_ptr(), R, nT, H, W, k, 0, 0, args.impl, st)), args.iters, 4), nb)
+            fm[i].data_ptr(), rois.data_ptr(), out[i].data_ptr(), R, nT, H, W, k, wf.data_ptr(), nfw, args.impl, st)), args.iters, 4), nb)
         emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "bwd", timed(lambda i: _check(L.d2t_psroipool_bwd_f32(
             go[i].data_ptr(), rois.data_ptr(), gin[i].data_ptr(), R, nT, H, W, k, wb.data_ptr(), nbw, args.impl, st)), args.iters, 4), nb)
 

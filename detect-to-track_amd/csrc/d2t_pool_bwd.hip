@@ -1,0 +1,555 @@
+// d2t_pool_bwd.hip -- gfx950-tuned f32 ROIPool / PSROIPool BACKWARD kernels (k = 7), and the
+// thread-per-output PSROIPool forward that serves small problems.
+//
+//  * ROIPool backward (gather form): gradOut is transposed once to (R, 49, C); a workgroup owns
+//    (64 channels, one map row), each of its waves walks a share of the RoIs -- work items come
+//    from a row-mask table, 64 RoIs per instruction, several in flight -- and adds gradOut/n into
+//    an LDS accumulator [W+1][65] that it alone touches (batched read-add-write, one channel per
+//    lane); the partial rows are added in a fixed order.
+//  * PSROIPool backward, phase 1: a workgroup owns one OUTPUT plane (t, bin) -- every plane has
+//    exactly R cells, so the grid is balanced whatever the many-to-one channel map
+//    ((t+1)*bin, ps_roipool_cuda.cu:58) does.  Its 4 waves own a quarter of the RoIs each and a
+//    private copy of the plane in LDS (k_psroipool_bwd_plane_lds; maps above 4096 pixels: bands of
+//    rows in registers, k_psroipool_bwd_plane).  64 RoIs are fetched per instruction (lane = RoI).
+//    Phase 2 adds, per input channel, the planes that map to it in ascending (bin, t) order.
+//  No accumulator is shared between waves, every gradIn element is written once, fixed summation
+//  order: bitwise reproducible.
+//
+// Round 2 tried to replace both with 2-D DIFFERENCE PLANES (g/n added at the four corners of a bin's
+// rectangle, then a 2-D prefix sum: 4 updates per bin instead of one per pixel; lanes whose corners
+// coincide serialised through a tag plane, no atomics).  Correct and deterministic, but it needs f64
+// planes (the +v / -v entries cancel only in the prefix sums; f32 planes missed the 1e-5 bar on small
+// maps with many RoIs), which leaves room for 4-6 wave planes per CU, and every update is a chain of
+// dependent LDS round trips (tag store, tag load, plane load, plane store): 346 us for ROIPool
+// config 3 against 176 us here, 367 us against 278 us for PSROIPool R=3000 nT=31.  DESIGN.md keeps
+// the numbers.
+#include "d2t_kernels.hpp"
+#include "d2t_tuned.hpp"
+#include <type_traits>
+
+namespace d2t { namespace tuned {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KT = 7;                         // r_hw the tuned pooling kernels are built for
+constexpr int KK = KT * KT;
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+inline size_t bins_bytes(int R) { return align256((size_t)R * KK * 4 * sizeof(int32_t)); }
+
+// ---------------------------------------------------------------------------------------
+// Per-RoI geometry record: 32 int32 = {i0[7], i1[7], j0[7], j1[7], top, bottom, left, right}.
+// Row bounds of a bin depend on i only, column bounds on j only (roipool_cuda.cu:41-50), so 28
+// numbers describe all 49 bins; one record is two s_load_dwordx16 for a wave.
+// ---------------------------------------------------------------------------------------
+constexpr int GEO = 32;
+inline size_t geo_bytes(int R) { return align256((size_t)R * GEO * sizeof(int32_t)); }
+
+__global__ void __launch_bounds__(64)
+k_roi_geom(const float* __restrict__ rois, int32_t* __restrict__ geo, uint8_t* __restrict__ rowmask,
+           float* __restrict__ rcp, int R, int H, int W)
+{
+    // one wave per RoI: lane i < 7 evaluates bin row i / bin column i, the tables are filled in parallel
+    const int r = blockIdx.x, lane = threadIdx.x;
+    int32_t* g = geo + (size_t)r * GEO;
+    Bounds b{0, 0, 0, 0};
+    if (lane < KT) b = roi_bin<float>(rois + 4 * r, lane, lane, H, W, KT);   // (i, i): row bounds of i, column bounds of j = i
+    int i0[KT], i1[KT], j0[KT], j1[KT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        i0[q] = __builtin_amdgcn_readlane(b.i0, q); i1[q] = __builtin_amdgcn_readlane(b.i1, q);
+        j0[q] = __builtin_amdgcn_readlane(b.j0, q); j1[q] = __builtin_amdgcn_readlane(b.j1, q);
+    }
+    if (lane < KT) { g[lane] = b.i0; g[KT + lane] = b.i1; g[2 * KT + lane] = b.j0; g[3 * KT + lane] = b.j1; }
+    if (lane == 0) { g[28] = i0[0]; g[29] = i1[KT - 1]; g[30] = j0[0]; g[31] = j1[KT - 1]; }
+    if (rowmask) {                                                   // bit i of rowmask[r][y]: bin row i contains map row y
+        for (int y = lane; y < H; y += 64) {
+            int mk = 0;
+#pragma unroll
+            for (int i = 0; i < KT; ++i) mk |= (y >= i0[i] && y < i1[i]) ? 1 << i : 0;
+            rowmask[(size_t)r * H + y] = (uint8_t)mk;
+        }
+    }
+    if (rcp && lane < KK) {                                          // 1 / binNumel of the 49 bins (0 for empty bins)
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < KT; ++i)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) n = lane == i * KT + j ? (i1[i] - i0[i]) * (j1[j] - j0[j]) : n;
+        rcp[(size_t)r * 64 + lane] = n > 0 ? 1.0f / static_cast<float>(n) : 0.f;
+    }
+}
+
+static int roi_geom(const float* rois, int32_t* geo, uint8_t* rowmask, float* rcp, int R, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_roi_geom, dim3(R), dim3(64), 0, st, rois, geo, rowmask, rcp, R, H, W);
+    return launch_status();
+}
+
+constexpr int RB_LD = 65;                                            // accumulator row stride (floats): lanes along x read it conflict-free
+
+
+// batched (C x 49) -> (49 x C) transpose: block = one RoI x 64 channels
+__global__ void __launch_bounds__(256)
+k_transpose_gout(const float* __restrict__ in, float* __restrict__ out, int C)
+{
+    __shared__ float t[64 * KK + 8];
+    const int r = blockIdx.x, c0 = blockIdx.y * 64;
+    const int nch = C - c0 < 64 ? C - c0 : 64;
+    const float* src = in + ((size_t)r * C + c0) * KK;
+    for (int e = threadIdx.x; e < nch * KK; e += 256) t[e] = src[e];
+    __syncthreads();
+    float* dst = out + (size_t)r * KK * C + c0;
+    for (int e = threadIdx.x; e < KK * 64; e += 256) {
+        const int b = e >> 6, ch = e & 63;
+        if (ch < nch) dst[(size_t)b * C + ch] = t[ch * KK + b];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ROIPool backward, channel-last gather.  gt: gradOut transposed to (R, 49, C).
+// Workgroup = (map row y, 64 channels), one channel per lane; wave w walks RoIs [w*R/NW,
+// (w+1)*R/NW) and adds into its own LDS accumulator [W+1][65] (row W is a dummy); the partial rows
+// are added in a fixed order and stored as 64 rows of gradIn.  A first version walked the RoIs with
+// scalar loads and added pixel by pixel (269 us at config 3: a chain of latencies); this one:
+//  * work items (RoI r, bin row i containing y) come out of a row-mask table, 64 RoIs per
+//    instruction (lane = RoI): no scalar load per RoI;
+//  * RC_PF items are in flight: geometry record, 7 reciprocals and the 7 x 256 bytes of
+//    (transposed) gradOut are fetched RC_PF items ahead of their use;
+//  * 1/binNumel comes from a table written by k_roi_geom (one multiply instead of a divide per
+//    bin: <= 1 ulp from gradOut/n, the reference's atomics leave the order undefined anyway);
+//  * the pixels of the even column bins (disjoint when the RoI is >= 7 pixels wide) are read
+//    together, added, written together, then the odd bins: 2 LDS round trips per item instead of
+//    one per pixel (27 on average).  Slots past a bin's width go to the dummy row.
+// Per pixel the order is ascending (r, i, j) within a wave; the waves' rows are added in order.
+// ---------------------------------------------------------------------------------------
+constexpr int RC_PF = 4;                                             // work items in flight per wave
+
+__global__ void __launch_bounds__(256)
+k_roipool_bwd_batched(const float* __restrict__ gt, const int32_t* __restrict__ geo, const uint8_t* __restrict__ rowmask,
+                      const float* __restrict__ rcp, float* __restrict__ gin, int R, int C, int H, int W)
+{
+    extern __shared__ float lds[];                                   // [waves][W+1][65]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int y = blockIdx.x, c0 = blockIdx.y * 64;
+    const int per = (W + 1) * RB_LD;
+    float* acc = lds + (size_t)wave * per + lane;
+    for (int x = 0; x <= W; ++x) acc[x * RB_LD] = 0.f;
+    const int cl = c0 + lane < C ? c0 + lane : C - 1;                // clamped lane channel (never stored)
+    const int r_lo = (int)((long long)R * wave / nw), r_hi = (int)((long long)R * (wave + 1) / nw);
+
+    // work-item generator; state is wave-uniform
+    int rb = r_lo - 64, cur = 0, mk = 0, bits = 0;
+    unsigned long long m = 0;
+    int nr = 0, ni = 0;
+    auto advance = [&]() -> bool {
+        for (;;) {
+            if (bits) {
+                ni = __builtin_ctz(bits);
+                bits &= bits - 1;
+                nr = rb + cur;
+                return true;
+            }
+            if (!m) {
+                if (rb + 64 >= r_hi) return false;
+                rb += 64;
+                mk = rb + lane < r_hi ? rowmask[(size_t)(rb + lane) * H + y] : 0;
+                m = __ballot(mk != 0);
+                continue;
+            }
+            cur = __builtin_ctzll(m);
+            m &= m - 1;
+            bits = __builtin_amdgcn_readlane(mk, cur);
+        }
+    };
+    struct Item { int rec; float rq; float v[KT]; };
+    auto fetch = [&](Item& it, int r, int i) {
+        it.rec = geo[(size_t)r * GEO + (lane & (GEO - 1))];          // the record, one int per lane
+        it.rq = rcp[(size_t)r * 64 + i * KT + (lane < KT ? lane : 0)];   // lanes 0..6: 1/n of the bin row's bins
+        const float* gr = gt + ((size_t)r * KK + i * KT) * C + cl;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) it.v[j] = gr[(size_t)j * C];    // 7 coalesced loads
+    };
+    auto add_item = [&](const Item& it) {
+        int j0[KT], w[KT];
+        float q[KT];
+        int wmax = 0;
+        bool regular = true;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            j0[j] = __builtin_amdgcn_readlane(it.rec, 2 * KT + j);
+            w[j] = __builtin_amdgcn_readlane(it.rec, 3 * KT + j) - j0[j];
+            wmax = w[j] > wmax ? w[j] : wmax;
+            q[j] = it.v[j] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, it.rq), j));
+        }
+#pragma unroll
+        for (int j = 0; j + 2 < KT; ++j) regular = regular && j0[j + 2] >= j0[j] + w[j];
+        auto batch = [&](auto sw_c, auto first_c) {                  // bins first, first+2, ..: SW slots each
+            constexpr int SW = decltype(sw_c)::value, FIRST = decltype(first_c)::value;
+            constexpr int NB = (KT - FIRST + 1) / 2;
+            float t[NB][SW];
+            int xo[NB][SW];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int s2 = 0; s2 < SW; ++s2) {
+                    const int j = FIRST + 2 * b;
+                    xo[b][s2] = (s2 < w[j] ? j0[j] + s2 : W) * RB_LD;   // wave-uniform; past the bin: dummy row
+                    t[b][s2] = acc[xo[b][s2]];
+                }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int s2 = 0; s2 < SW; ++s2) acc[xo[b][s2]] = t[b][s2] + q[FIRST + 2 * b];
+        };
+        using std::integral_constant;
+        if (regular && wmax <= 4) {
+            batch(integral_constant<int, 4>{}, integral_constant<int, 0>{});
+            batch(integral_constant<int, 4>{}, integral_constant<int, 1>{});
+        } else if (regular && wmax <= 8) {
+            batch(integral_constant<int, 8>{}, integral_constant<int, 0>{});
+            batch(integral_constant<int, 8>{}, integral_constant<int, 1>{});
+        } else {                                                     // tiny or very wide RoIs: pixel by pixel
+#pragma unroll 1
+            for (int j = 0; j < KT; ++j)
+#pragma unroll 1
+                for (int x = j0[j]; x < j0[j] + w[j]; ++x) acc[x * RB_LD] += q[j];
+        }
+    };
+    Item it[RC_PF];
+    bool ok[RC_PF];
+#pragma unroll
+    for (int s = 0; s < RC_PF; ++s) {
+        ok[s] = advance();
+        if (ok[s]) fetch(it[s], nr, ni);
+    }
+    while (ok[0]) {                                                  // slots are consumed round-robin = in item order
+#pragma unroll
+        for (int s = 0; s < RC_PF; ++s) {
+            if (ok[s]) {
+                add_item(it[s]);
+                ok[s] = advance();
+                if (ok[s]) fetch(it[s], nr, ni);
+            }
+        }
+    }
+    __syncthreads();
+    // gin[c0+ch][y][0..W): lanes along x, fixed-order sum of the waves' partial rows
+    const int nch = C - c0 < 64 ? C - c0 : 64;
+    for (int e = threadIdx.x; e < nch * W; e += blockDim.x) {
+        const int ch = e / W, x = e - ch * W;
+        const int o = x * RB_LD + ch;
+        float a = lds[o];
+        for (int wv = 1; wv < nw; ++wv) a += lds[(size_t)wv * per + o];
+        gin[((size_t)(c0 + ch) * H + y) * W + x] = a;
+    }
+}
+
+bool roipool_bwd_supported(int R, int C, int H, int W, int k)
+{
+    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && (C + 63) / 64 <= 65535 &&
+           (size_t)(W + 1) * RB_LD * sizeof(float) <= 64 * 1024;
+}
+
+size_t roipool_bwd_ws_bytes(int R, int C, int H, int W, int k)
+{
+    if (!roipool_bwd_supported(R, C, H, W, k)) return 0;
+    return align256((size_t)R * C * KK * sizeof(float)) + geo_bytes(R) + align256((size_t)R * H) +
+           align256((size_t)R * 64 * sizeof(float));
+}
+
+int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int,
+                    void* ws, hipStream_t st)
+{
+    float* gt = static_cast<float*>(ws);
+    int32_t* geo = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + align256((size_t)R * C * KK * sizeof(float)));
+    hipLaunchKernelGGL(k_transpose_gout, dim3(R, (C + 63) / 64), dim3(256), 0, st, gout, gt, C);   // (R,C,49) -> (R,49,C)
+    int rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    uint8_t* rowmask = reinterpret_cast<uint8_t*>(geo) + geo_bytes(R);
+    float* rcp = reinterpret_cast<float*>(rowmask + align256((size_t)R * H));
+    rc = roi_geom(rois, geo, rowmask, rcp, R, H, W, st);
+    if (rc != D2T_OK) return rc;
+    const dim3 grid(H, (C + 63) / 64);
+    const size_t acc_bytes = (size_t)(W + 1) * RB_LD * sizeof(float);
+    int waves = (int)(64 * 1024 / acc_bytes);                        // private accumulators that fit 64 KB of LDS
+    waves = waves > 4 ? 4 : waves;
+    hipLaunchKernelGGL(k_roipool_bwd_batched, grid, dim3(64 * waves), waves * acc_bytes, st,
+                       gt, geo, rowmask, rcp, gin, R, C, H, W);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// PSROIPool forward.  Workgroup = (RoI, 256 consecutive outputs (t, bin)).  The RoI's 49 cells
+// are evaluated once per workgroup (lanes 0..48, double-precision bin centres as the reference)
+// and shared through LDS instead of once per output; a thread then sums its cell row by row:
+// the pixels of a row are fetched with 8 independent (clamped) loads and added in ascending x, so
+// the dependent chain is the cell's rows, not its pixels.  The running sum sees the pixels in the
+// reference's order (ps_roipool_cuda.cu:60-66) and the guarded IEEE divide is kept: bit-identical.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_psroipool_fwd_roi(const float* __restrict__ fm, const float* __restrict__ rois, float* __restrict__ out,
+                    int nT, int H, int W)
+{
+    __shared__ int4 cells[KK];
+    const int r = blockIdx.x;
+    if (threadIdx.x < KK) {
+        const int i = threadIdx.x / KT, j = threadIdx.x - i * KT;
+        const Bounds c = psroi_cell<float>(rois + 4 * (size_t)r, i, j, H, W, KT);
+        cells[threadIdx.x] = make_int4(c.i0, c.i1, c.j0, c.j1);
+    }
+    __syncthreads();
+    const int e = blockIdx.y * 256 + threadIdx.x;                    // output (t, bin) of this RoI
+    if (e >= nT * KK) return;
+    const int t = e / KK, bin = e - t * KK;
+    const int4 c = cells[bin];
+    const float* ch = fm + (size_t)((t + 1) * bin) * H * W;          // ps_roipool_cuda.cu:58
+    const int w = c.w - c.z;
+    float acc = 0.f;
+    for (int y = c.x; y < c.y; ++y) {
+        const float* row = ch + y * W + c.z;
+        for (int x0 = 0; x0 < w; x0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = row[x0 + k < w ? x0 + k : w - 1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (x0 + k < w) acc += v[k];                         // ascending x
+        }
+    }
+    const int n = (c.y - c.x) * w;
+    if (n > 0) acc /= static_cast<float>(n);                         // guarded divide, :68
+    out[(size_t)r * nT * KK + e] = acc;
+}
+
+int psroipool_fwd_small_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int,
+                      hipStream_t st)
+{
+    hipLaunchKernelGGL(k_psroipool_fwd_roi, dim3(R, (nT * KK + 255) / 256), dim3(256), 0, st, fm, rois, out, nT, H, W);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Pixel ownership of the PSROIPool backward: 4 waves x bands of <= PX_ROWS rows, lane = column
+// (two column groups for maps wider than 64).
+// ---------------------------------------------------------------------------------------
+constexpr int PX_MAXROWS = 16;               // rows per wave band: H <= 64
+constexpr int PX_XG = 2;                     // column groups: W <= 128
+
+// ---------------------------------------------------------------------------------------
+// PSROIPool backward, phase 1.  Workgroup = output plane (t, bin).  cells: (R,7,7,4) int32.
+// part[plane][y][x] = sum over RoIs r whose cell `bin` contains (y,x) of gout[r,t,bin] / n
+// (ps_roipool_cuda.cu:131-139), ascending r.
+// ---------------------------------------------------------------------------------------
+template <int PX_ROWS>                       // band height the row loop is unrolled for (10: H <= 40)
+__global__ void __launch_bounds__(256)
+k_psroipool_bwd_plane(const float* __restrict__ gout, const int32_t* __restrict__ cells, float* __restrict__ part,
+                      int R, int nT, int H, int W)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int plane = blockIdx.x, bin = plane % KK;                  // plane = t*49 + bin
+    const int band = (H + 3) >> 2;
+    const int y_lo = wave * band, y_hi = y_lo + band < H ? y_lo + band : H;
+    float acc[PX_ROWS][PX_XG];
+#pragma unroll
+    for (int k = 0; k < PX_ROWS; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; }
+
+    if (y_lo < y_hi) {
+        const int4* ct = reinterpret_cast<const int4*>(cells) + bin;
+        const float* gp = gout + plane;
+        for (int rb = 0; rb < R; rb += 64) {
+            // 64 RoIs per instruction: lane l fetches and tests RoI rb+l
+            const int rr = rb + lane;
+            int4 cb = make_int4(0, 0, 0, 0);
+            float v = 0.f;
+            if (rr < R) {
+                cb = ct[(size_t)rr * KK];
+                v = gp[(size_t)rr * nT * KK];
+            }
+            const int n = (cb.y - cb.x) * (cb.w - cb.z);
+            const bool hit = cb.y > cb.x && cb.w > cb.z && cb.y > y_lo && cb.x < y_hi;
+            v = v / static_cast<float>(n > 0 ? n : 1);               // ps_roipool_cuda.cu:135
+            unsigned long long m = __ballot(hit);
+            while (m) {                                              // ascending r
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int i0 = __builtin_amdgcn_readlane(cb.x, l), i1 = __builtin_amdgcn_readlane(cb.y, l);
+                const int j0 = __builtin_amdgcn_readlane(cb.z, l), j1 = __builtin_amdgcn_readlane(cb.w, l);
+                const float vv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                const float v0 = (lane >= j0 && lane < j1) ? vv : 0.f;
+                const float v1 = (lane + 64 >= j0 && lane + 64 < j1) ? vv : 0.f;
+#pragma unroll
+                for (int k = 0; k < PX_ROWS; ++k) {
+                    const int y = y_lo + k;
+                    if (y >= i0 && y < i1 && y < y_hi) { acc[k][0] += v0; acc[k][1] += v1; }   // wave-uniform
+                }
+            }
+        }
+    }
+    float* dst = part + (size_t)plane * H * W;
+#pragma unroll
+    for (int k = 0; k < PX_ROWS; ++k) {
+        const int y = y_lo + k;
+        if (y < y_hi) {
+            if (lane < W) dst[y * W + lane] = acc[k][0];
+            if (lane + 64 < W) dst[y * W + lane + 64] = acc[k][1];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// PSROIPool backward, phase 1, LDS form (maps up to 4096 pixels).  Workgroup = output plane
+// (t, bin); each of the 4 waves owns a quarter of the RoIs and a PRIVATE copy of the plane in LDS.
+// 64 RoIs are fetched per instruction (lane = RoI) and their cells computed on the fly (no cell
+// table, no extra launch).  Two ways to add them, chosen by the launcher:
+//   SWEEP = false  every non-empty cell in turn (ascending r) by the lanes of an 8 x 8 grid laid
+//                  over it: one LDS read-add-write of <= 64 pixels, ~25 instructions per cell (the
+//                  register-band form above needs ~80: it tests all of its rows against every cell);
+//   SWEEP = true   all 64 cells together, pixel (dy, dx) of every cell per step, with ds_add_f32
+//                  on the wave-private plane: ~5 instructions per cell but ~3.4 cycles per lane in
+//                  the LDS -- wins when there are too few planes to hide the per-cell latency.
+// Each wave adds its RoIs in ascending order, the four copies are summed in wave order.
+// ---------------------------------------------------------------------------------------
+constexpr int PL_WAVES = 4;
+constexpr int PL_MAXPIX = 4096;                                      // 4 planes x 16 KB = 64 KB of LDS
+
+template <bool SWEEP>
+__global__ void __launch_bounds__(PL_WAVES * 64)
+k_psroipool_bwd_plane_lds(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ part,
+                          int R, int nT, int H, int W)
+{
+    extern __shared__ float planes[];                                // [PL_WAVES][H*W]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int plane = blockIdx.x, bin = plane % KK, HW = H * W;      // plane = t*49 + bin
+    float* mine = planes + wave * HW;
+    for (int e = lane; e < HW; e += 64) mine[e] = 0.f;
+    const int dy = lane >> 3, dx = lane & 7, loff = dy * W + dx;
+    const int r_lo = (int)((long long)R * wave / PL_WAVES), r_hi = (int)((long long)R * (wave + 1) / PL_WAVES);
+    const int bi = bin / KT, bj = bin - bi * KT;
+    const float* gp = gout + plane;
+    for (int rb = r_lo; rb < r_hi; rb += 64) {
+        const int rr = rb + lane;
+        int4 cb = make_int4(0, 0, 0, 0);                             // (i0, i1, j0, j1) of this RoI's cell
+        float v = 0.f;
+        if (rr < r_hi) {
+            const Bounds c = psroi_cell<float>(rois + 4 * (size_t)rr, bi, bj, H, W, KT);
+            cb = make_int4(c.i0, c.i1, c.j0, c.j1);
+            v = gp[(size_t)rr * nT * KK];
+        }
+        const int n = (cb.y - cb.x) * (cb.w - cb.z);
+        const bool hit = cb.y > cb.x && cb.w > cb.z;
+        v = v / static_cast<float>(n > 0 ? n : 1);                   // ps_roipool_cuda.cu:135
+        if (SWEEP) {
+            // lane = RoI: the 64 cells are swept together, pixel (dy, dx) of every cell per step, with
+            // LDS float adds (the plane is private to the wave: no contention, fixed order)
+            const int h = hit ? cb.y - cb.x : 0, w = cb.w - cb.z;
+            float* p = mine + cb.x * W + cb.z;
+            for (int sy = 0; __ballot(sy < h); ++sy)
+                for (int sx = 0; __ballot(sy < h && sx < w); ++sx)
+                    if (sy < h && sx < w)
+                        __hip_atomic_fetch_add(p + sy * W + sx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            continue;
+        }
+        // cells are visited one at a time in ascending r; the lanes form an 8 x 8 grid laid over the
+        // cell: one LDS read-add-write covers it (larger cells take more grid positions)
+        const int base = cb.x * W + cb.z;
+        const int hw = ((cb.y - cb.x) << 16) | (cb.w - cb.z);
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int sb = __builtin_amdgcn_readlane(base, l), shw = __builtin_amdgcn_readlane(hw, l);
+            const float vv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+            const int h = shw >> 16, w = shw & 0xffff;
+            float* p = mine + sb + loff;
+            if (h <= 8 && w <= 8) {                                  // wave-uniform: the usual case
+                if (dy < h && dx < w) *p += vv;
+            } else {
+                for (int ty = 0; ty < h; ty += 8)
+                    for (int tx = 0; tx < w; tx += 8)
+                        if (ty + dy < h && tx + dx < w) p[ty * W + tx] += vv;
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = part + (size_t)plane * HW;
+    for (int e = threadIdx.x; e < HW; e += PL_WAVES * 64)
+        dst[e] = ((planes[e] + planes[HW + e]) + planes[2 * HW + e]) + planes[3 * HW + e];
+}
+
+// Phase 2: the planes that map to an input channel are (t, bin) with (t+1)*bin == ch, i.e. bin | ch
+// with ch/bin <= nT (ps_roipool_cuda.cu:58); channel 0 collects bin 0 of every t.  Each workgroup
+// finds its channel's planes itself (ascending bin) and adds them in that fixed order.
+
+// phase 2: gin[ch] = sum of the planes that map to ch, ascending bin then t; channels nothing
+// maps to are zero.
+__global__ void __launch_bounds__(256)
+k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, int nT, int HW)
+{
+    // planes (t, bin) with (t+1)*bin == ch, ascending bin: lane b-1 of the first wave tests bin b
+    __shared__ int32_t srcs[KK];
+    __shared__ int nsrc;
+    const int ch = blockIdx.y;
+    if (threadIdx.x < 64) {
+        const int bin = threadIdx.x + 1;
+        const bool is_src = ch > 0 && bin < KK && ch % bin == 0 && ch / bin <= nT;
+        const unsigned long long m = __ballot(is_src);
+        if (is_src) srcs[__builtin_popcountll(m & ((1ull << threadIdx.x) - 1ull))] = (ch / bin - 1) * KK + bin;
+        if (threadIdx.x == 0) nsrc = __builtin_popcountll(m);
+    }
+    __syncthreads();
+    const int ns = nsrc;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        float a = 0.f;
+        if (ch == 0) {                                               // bin 0 of every target
+            for (int t = 0; t < nT; ++t) a += part[(size_t)(t * KK) * HW + p];
+        } else {
+            for (int k = 0; k < ns; ++k) a += part[(size_t)srcs[k] * HW + p];
+        }
+        gin[(size_t)ch * HW + p] = a;
+    }
+}
+
+bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
+{
+    return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && H <= 4 * PX_MAXROWS && W <= 64 * PX_XG && nT * KK <= 65535;
+}
+
+size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
+{
+    if (!psroipool_bwd_supported(R, nT, H, W, k)) return 0;
+    return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float));
+}
+
+int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
+                      void* ws, hipStream_t st)
+{
+    int32_t* cells = static_cast<int32_t*>(ws);                      // only the register-band form reads a cell table
+    float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + bins_bytes(R));
+    int rc;
+    if (H * W <= PL_MAXPIX) {
+        // few planes (< 2 workgroups per CU): one wave per SIMD, latency-bound -> sweep 64 cells at a time;
+        // many planes: the LDS float-add rate (~3.4 cycles per lane) would bound -> per-cell read-add-write
+        if (nT * KK < 512)
+            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<true>, dim3(nT * KK), dim3(PL_WAVES * 64),
+                               (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
+        else
+            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<false>, dim3(nT * KK), dim3(PL_WAVES * 64),
+                               (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
+    } else {
+        rc = psroipool_bins<float>(rois, cells, R, H, W, k, st);
+        if (rc != D2T_OK) return rc;
+        if (H <= 40)
+            hipLaunchKernelGGL(k_psroipool_bwd_plane<10>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
+        else
+            hipLaunchKernelGGL(k_psroipool_bwd_plane<PX_MAXROWS>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
+    }
+    rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    const int HW = H * W;
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
+    return launch_status();
+}
+
+}}  // namespace d2t::tuned

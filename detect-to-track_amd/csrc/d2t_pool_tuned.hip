@@ -1,680 +1,423 @@
-// d2t_pool_tuned.hip -- gfx950-tuned f32 ROIPool / PSROIPool kernels (k = 7).
+// d2t_pool_tuned.hip -- gfx950-tuned f32 ROIPool / PSROIPool FORWARD kernels (k = 7).
 //
 // The pooling ops are byte movers (ROIPool config 3: 60 MB of output against 10 MB of input and
-// ~0 flops), so the design goal is coalescing, not arithmetic:
+// ~0 flops; PSROIPool at the model's shapes: 17 MB of map against 2 MB of output).  Round 1 gathered
+// every bin's pixels from L2 / L1 and scattered every gradient into its pixels; both were bound by
+// the number of memory and LDS instructions, 10-60x off the HBM roof.  This version keeps the
+// feature map (or its gradient) of a few channels resident in LDS and touches every RoI bin a
+// constant number of times:
 //
-//  * ROIPool works CHANNEL-LAST.  A pre-pass transposes the (C,H,W) map to (H*W, C) in the
-//    workspace; then one wave owns (RoI, 64 consecutive channels) with one channel per lane.
-//    Every bin bound is wave-uniform (scalar registers, scalar loads from the bin table), every
-//    feature load is a full 256-byte row of 64 channels of one pixel, and each lane keeps the
-//    reference's running sum over its bin in the reference's own pixel order (roipool_cuda.cu:56-61)
-//    -- forward results stay BIT-IDENTICAL to the reference.  The 64 x 49 results of a wave are
-//    exactly one contiguous 12.5 KB run of the (R,C,7,7) output; they are transposed through LDS
-//    and stored as full 256-byte rows.
-//  * ROIPool backward (gather form): gradOut is transposed once to (R, 49, C); a workgroup owns
-//    (64 channels, one map row), each of its waves walks a share of the RoIs -- work items come
-//    from a row-mask table, 64 RoIs per instruction, several in flight -- and adds gradOut/n into
-//    an LDS accumulator [W+1][65] that it alone touches (batched read-add-write, one channel per
-//    lane); the partial rows are added in a fixed order.
-//  * PSROIPool backward, phase 1: a workgroup owns one OUTPUT plane (t, bin) -- every plane has
-//    exactly R cells, so the grid is balanced whatever the many-to-one channel map
-//    ((t+1)*bin, ps_roipool_cuda.cu:58) does.  Its 4 waves own a quarter of the RoIs each and a
-//    private copy of the plane in LDS (k_psroipool_bwd_plane_lds; maps above 4096 pixels: bands of
-//    rows in registers, k_psroipool_bwd_plane).  64 RoIs are fetched per instruction (lane = RoI).
-//    Phase 2 adds, per input channel, the planes that map to it in ascending (bin, t) order.
-//  No accumulator is shared between waves (the one ds_add_f32 use is on a wave-private plane:
-//  in-order, no contention), every gradIn
-//  element written once, fixed summation order: bitwise reproducible.
+//  * ROIPool forward: a workgroup builds the SUMMED-AREA TABLE of 1-4 channels in LDS (f64: exact to
+//    2^-53 of the table's magnitude) and every output is four table look-ups, whatever the bin's
+//    size.  The reference sums a bin in f32 in row-major order (roipool_cuda.cu:56-61); the table
+//    gives the exactly rounded sum instead, so values agree to f32 rounding of the reference's own
+//    running sum (tests: |delta| <= 1e-5 abs/rel, the contract of BASELINE.json) -- the type-generic
+//    kernel remains the bit-exact form.  Empty bins give 0/0 = NaN like the reference; a non-finite
+//    result (Inf / NaN somewhere in the channel poisons the table) is recomputed in the reference's
+//    form from global memory.
+//  * PSROIPool forward keeps the reference's running sum (ps_roipool_cuda.cu:60-66): a workgroup
+//    stages ONE input channel in LDS and evaluates every output (t, bin) that reads it, for a chunk
+//    of RoIs, lane = RoI; results go to a (t*49+bin, RoI) buffer and are transposed to (RoI, t, bin).
+//    Bit-identical to the reference.
+//  The backward kernels live in d2t_pool_bwd.hip.
 #include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
-#include <type_traits>
 
 namespace d2t { namespace tuned {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int KT = 7;                         // r_hw the tuned pooling kernels are built for
 constexpr int KK = KT * KT;
+constexpr int LDS_MAX = 160 * 1024;           // bytes of LDS a workgroup may use on gfx950
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-inline size_t bins_bytes(int R) { return align256((size_t)R * KK * 4 * sizeof(int32_t)); }
 
 // ---------------------------------------------------------------------------------------
-// (rows, cols) -> (cols, rows) transpose of a row-major f32 matrix, 32x32 tiles through LDS.
+// (rows, cols) -> (cols, rows) transpose of a row-major f32 matrix, 32x32 tiles through LDS;
+// the tiles are walked by a 1-D grid (no 65535 limit on either extent).
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows, int cols)
+k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int tiles_c, long long ntiles)
 {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int c0 = (int)(t % tiles_c) * 32, r0 = (int)(t / tiles_c) * 32;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = r0 + ty + 8 * k, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + 8 * k][tx] = in[(size_t)r * cols + c];
-    }
-    __syncthreads();
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            if (r < rows && c < cols) tile[ty + 8 * k][tx] = in[(size_t)r * cols + c];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][ty + 8 * k];
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][ty + 8 * k];
+        }
+        __syncthreads();
     }
 }
 
 static int transpose(const float* in, float* out, int rows, int cols, hipStream_t st)
 {
     if (rows == 0 || cols == 0) return D2T_OK;
-    hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows, cols);
+    const int tiles_c = (cols + 31) / 32;
+    const long long ntiles = 1LL * tiles_c * ((rows + 31) / 32);
+    const int grid = (int)(ntiles < 256 * 64 ? ntiles : 256 * 64);
+    hipLaunchKernelGGL(k_transpose, dim3(grid), dim3(256), 0, st, in, out, rows, cols, tiles_c, ntiles);
     return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
-// Per-RoI geometry record: 32 int32 = {i0[7], i1[7], j0[7], j1[7], top, bottom, left, right}.
-// Row bounds of a bin depend on i only, column bounds on j only (roipool_cuda.cu:41-50), so 28
-// numbers describe all 49 bins; one record is two s_load_dwordx16 for a wave.
+// ROIPool geometry: per RoI 32 bytes = {(i0,i1)[7], (j0,j1)[7], 4 pad}: byte 2i = i0 of bin row i,
+// 2i+1 = its i1, byte 14+2j = j0 of bin column j, 15+2j = its j1 (one 16-bit load per axis).  Row
+// bounds of a bin depend on i only, column bounds on j only (roipool_cuda.cu:41-50), so 28 numbers
+// describe all 49 bins; every bound lies in [0, 255] (maps above 255 rows or columns take the generic
+// kernels).
 // ---------------------------------------------------------------------------------------
-constexpr int GEO = 32;
-inline size_t geo_bytes(int R) { return align256((size_t)R * GEO * sizeof(int32_t)); }
+constexpr int GEO8 = 32;
+inline size_t geo8_bytes(int R) { return align256((size_t)R * GEO8); }
 
 __global__ void __launch_bounds__(64)
-k_roi_geom(const float* __restrict__ rois, int32_t* __restrict__ geo, uint8_t* __restrict__ rowmask,
-           float* __restrict__ rcp, int R, int H, int W)
+k_roi_geom8(const float* __restrict__ rois, uint32_t* __restrict__ geo8, int R, int H, int W)
 {
-    // one wave per RoI: lane i < 7 evaluates bin row i / bin column i, the tables are filled in parallel
-    const int r = blockIdx.x, lane = threadIdx.x;
-    int32_t* g = geo + (size_t)r * GEO;
-    Bounds b{0, 0, 0, 0};
-    if (lane < KT) b = roi_bin<float>(rois + 4 * r, lane, lane, H, W, KT);   // (i, i): row bounds of i, column bounds of j = i
-    int i0[KT], i1[KT], j0[KT], j1[KT];
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    uint32_t w[GEO8 / 4] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto put = [&](int k, int v) { w[k >> 2] |= (uint32_t)(v & 255) << (8 * (k & 3)); };
 #pragma unroll
     for (int q = 0; q < KT; ++q) {
-        i0[q] = __builtin_amdgcn_readlane(b.i0, q); i1[q] = __builtin_amdgcn_readlane(b.i1, q);
-        j0[q] = __builtin_amdgcn_readlane(b.j0, q); j1[q] = __builtin_amdgcn_readlane(b.j1, q);
+        const Bounds b = roi_bin<float>(rois + 4 * (size_t)r, q, q, H, W, KT);   // (q, q): row bounds of i = q, column bounds of j = q
+        put(2 * q, b.i0); put(2 * q + 1, b.i1); put(2 * KT + 2 * q, b.j0); put(2 * KT + 2 * q + 1, b.j1);
     }
-    if (lane < KT) { g[lane] = b.i0; g[KT + lane] = b.i1; g[2 * KT + lane] = b.j0; g[3 * KT + lane] = b.j1; }
-    if (lane == 0) { g[28] = i0[0]; g[29] = i1[KT - 1]; g[30] = j0[0]; g[31] = j1[KT - 1]; }
-    if (rowmask) {                                                   // bit i of rowmask[r][y]: bin row i contains map row y
-        for (int y = lane; y < H; y += 64) {
-            int mk = 0;
 #pragma unroll
-            for (int i = 0; i < KT; ++i) mk |= (y >= i0[i] && y < i1[i]) ? 1 << i : 0;
-            rowmask[(size_t)r * H + y] = (uint8_t)mk;
-        }
-    }
-    if (rcp && lane < KK) {                                          // 1 / binNumel of the 49 bins (0 for empty bins)
-        int n = 0;
-#pragma unroll
-        for (int i = 0; i < KT; ++i)
-#pragma unroll
-            for (int j = 0; j < KT; ++j) n = lane == i * KT + j ? (i1[i] - i0[i]) * (j1[j] - j0[j]) : n;
-        rcp[(size_t)r * 64 + lane] = n > 0 ? 1.0f / static_cast<float>(n) : 0.f;
-    }
+    for (int k = 0; k < GEO8 / 4; ++k) geo8[(size_t)r * (GEO8 / 4) + k] = w[k];
 }
 
-static int roi_geom(const float* rois, int32_t* geo, uint8_t* rowmask, float* rcp, int R, int H, int W, hipStream_t st)
+static int roi_geom8(const float* rois, void* geo8, int R, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_roi_geom, dim3(R), dim3(64), 0, st, rois, geo, rowmask, rcp, R, H, W);
+    if (R == 0) return D2T_OK;
+    hipLaunchKernelGGL(k_roi_geom8, dim3((R + 63) / 64), dim3(64), 0, st, rois, static_cast<uint32_t*>(geo8), R, H, W);
     return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
-// ROIPool forward, channel-last.  fmt: (H*W, C).  Workgroup = (RoI, 64 channels) = 7 waves, wave
-// i owns bin row i: 7 accumulators (one per bin column) per lane, one channel per lane.  The
-// column loops of the 7 bins advance together (step k = k-th pixel of every bin), so 7 independent
-// 256-byte loads are in flight per step while each accumulator still sees its bin's pixels in the
-// reference's row-major order.  The 64 x 49 block is assembled in LDS and stored as one
-// contiguous 12.5 KB run.
-// ---------------------------------------------------------------------------------------
-constexpr int RF_THREADS = KT * 64;
-
-__global__ void __launch_bounds__(RF_THREADS)
-k_roipool_fwd_cl(const float* __restrict__ fmt, const int32_t* __restrict__ geo, float* __restrict__ out,
-                 int C, int W)
+// In-place inclusive 2-D prefix sum of nb f64 maps F[b][H][LDW] (columns 0..W-1), all threads of the
+// workgroup: along x in segments of 16 plus a fix-up with the totals of the segments to the left,
+// then along y in segments of 8 the same way (a thread's steps are independent LDS accesses, the
+// running sum stays in a register).  scr: nb * (H*nsx + nsy*W) doubles.
+constexpr int PX_SEG = 16, PY_SEG = 8;
+__device__ __forceinline__ int prefix_scratch_doubles(int nb, int H, int W)
 {
-    __shared__ __attribute__((aligned(16))) float stage[64 * KK + 16];   // 12.6 KB
-    const int lane = threadIdx.x & 63;
-    const int i = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index = bin row (wave-uniform)
-    const int r = blockIdx.x, c0 = blockIdx.y * 64;
-    const int c = c0 + lane < C ? c0 + lane : C - 1;                 // clamped lane channel; masked at the store
-    const int32_t* g = geo + (size_t)r * GEO;
-    const int i0 = __builtin_amdgcn_readfirstlane(g[i]), i1 = __builtin_amdgcn_readfirstlane(g[KT + i]);
-    int j0[KT], wj[KT], wmax = 0;
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        j0[j] = __builtin_amdgcn_readfirstlane(g[2 * KT + j]);
-        wj[j] = __builtin_amdgcn_readfirstlane(g[3 * KT + j]) - j0[j];
-        wmax = wj[j] > wmax ? wj[j] : wmax;
-    }
-    float acc[KT];
-#pragma unroll
-    for (int j = 0; j < KT; ++j) acc[j] = 0.f;
-    const float* base = fmt + c;
-    for (int pI = i0; pI < i1; ++pI) {
-        const float* row = base + (size_t)pI * W * C;
-        for (int k = 0; k < wmax; ++k) {
-            float v[KT];
-#pragma unroll
-            for (int j = 0; j < KT; ++j) {                           // 7 independent loads; a bin that is
-                int col = j0[j] + (k < wj[j] ? k : 0);               // already exhausted re-reads its first
-                col = wj[j] > 0 ? col : 0;                           // pixel (or pixel 0) and adds an exact 0
-                v[j] = row[(size_t)col * C];
-            }
-#pragma unroll
-            for (int j = 0; j < KT; ++j) acc[j] += k < wj[j] ? v[j] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        const int n = (i1 - i0) * wj[j];
-        stage[lane * KK + i * KT + j] = acc[j] / static_cast<float>(n);     // 0/0 = NaN as the reference
+    return nb * (H * ((W + PX_SEG - 1) / PX_SEG) + ((H + PY_SEG - 1) / PY_SEG) * W);
+}
+inline size_t prefix_scratch_bytes(int nb, int H, int W)
+{
+    return (size_t)nb * ((size_t)H * ((W + PX_SEG - 1) / PX_SEG) + (size_t)((H + PY_SEG - 1) / PY_SEG) * W) * 8;
+}
+
+__device__ __forceinline__ void prefix2d(double* __restrict__ F, double* __restrict__ scr, int nb, int H, int W, int LDW,
+                                         int mstride /* doubles between maps */, int tid, int nthr)
+{
+    const int nsx = (W + PX_SEG - 1) / PX_SEG, nsy = (H + PY_SEG - 1) / PY_SEG;
+    const int ntx = nb * H * nsx;
+    for (int t = tid; t < ntx; t += nthr) {
+        const int row = t / nsx, sg = t - row * nsx, bb = row / H, y = row - bb * H;
+        double* p = F + (size_t)bb * mstride + y * LDW;
+        const int x0 = sg * PX_SEG, x1 = x0 + PX_SEG < W ? x0 + PX_SEG : W;
+        double run = 0.0;
+        for (int x = x0; x < x1; ++x) { run += p[x]; p[x] = run; }
+        scr[t] = run;
     }
     __syncthreads();
-    // the workgroup's 64 x 49 block is one contiguous, 16-byte aligned run of out: 16-byte
-    // WRITE-THROUGH stores (sc1), so the 60 MB of output drain to HBM while other workgroups still
-    // pool instead of sitting dirty in L2 until the kernel ends
-    const int nch = C - c0 < 64 ? C - c0 : 64;
-    float* dst = out + ((size_t)r * C + c0) * KK;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (unsigned)nch * KK * 4u, 0x00020000);
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const int n4 = (nch * KK) >> 2;
-    for (int e = threadIdx.x; e < n4; e += RF_THREADS)
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(stage + 4 * e), ro, e * 16, 0, 16);
-    for (int e = 4 * n4 + threadIdx.x; e < nch * KK; e += RF_THREADS) dst[e] = stage[e];
+    for (int t = tid; t < ntx; t += nthr) {
+        const int row = t / nsx, sg = t - row * nsx;
+        if (sg == 0) continue;
+        double off = 0.0;
+        for (int s2 = 0; s2 < sg; ++s2) off += scr[row * nsx + s2];
+        const int bb = row / H, y = row - bb * H;
+        double* p = F + (size_t)bb * mstride + y * LDW;
+        const int x0 = sg * PX_SEG, x1 = x0 + PX_SEG < W ? x0 + PX_SEG : W;
+        for (int x = x0; x < x1; ++x) p[x] += off;
+    }
+    __syncthreads();
+    double* scy = scr + ntx;
+    const int nty = nb * nsy * W;
+    for (int t = tid; t < nty; t += nthr) {
+        const int bs = t / W, x = t - bs * W, bb = bs / nsy, sg = bs - bb * nsy;   // consecutive threads: consecutive columns
+        double* p = F + (size_t)bb * mstride + x;
+        const int y0 = sg * PY_SEG, y1 = y0 + PY_SEG < H ? y0 + PY_SEG : H;
+        double run = 0.0;
+        for (int y = y0; y < y1; ++y) { run += p[y * LDW]; p[y * LDW] = run; }
+        scy[t] = run;
+    }
+    __syncthreads();
+    for (int t = tid; t < nty; t += nthr) {
+        const int bs = t / W, x = t - bs * W, bb = bs / nsy, sg = bs - bb * nsy;
+        if (sg == 0) continue;
+        double off = 0.0;
+        for (int s2 = 0; s2 < sg; ++s2) off += scy[(bb * nsy + s2) * W + x];
+        double* p = F + (size_t)bb * mstride + x;
+        const int y0 = sg * PY_SEG, y1 = y0 + PY_SEG < H ? y0 + PY_SEG : H;
+        for (int y = y0; y < y1; ++y) p[y * LDW] += off;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// ROIPool forward: summed-area tables in LDS.
+// Workgroup = (CG consecutive channels, a share of the RoIs), 1024 threads.
+//   sat[c][y][x] (f64) = sum of FM[c][0..y-1][0..x-1]; row pitch LD is odd (rows land on different
+//   banks), row 0 and column 0 are zero.  Built by a coalesced load and prefix2d.
+//   An output is (S(i1,j1) - S(i0,j1)) - (S(i1,j0) - S(i0,j0)) rounded to f32 times 1/n (v_rcp_f32:
+//   1 ulp; 0 * inf = NaN for an empty bin as the reference's 0/0, roipool_cuda.cu:61).  980 threads
+//   work: thread t owns element t mod (CG*49) of a RoI's output run for good -- its (channel, bin
+//   row, bin column) never change, no index arithmetic in the loop -- and walks the RoIs 980/(CG*49)
+//   at a time.  Consecutive threads produce consecutive elements of out: contiguous runs of CG*196
+//   bytes per RoI.
+// ---------------------------------------------------------------------------------------
+constexpr int RF_THREADS = 1024;
+constexpr int RF_ACTIVE = 980;                // 20 * 49 = 10 * 98 = 5 * 196
+constexpr int RF_RC = 240;                    // RoIs whose geometry is staged in LDS at a time (a multiple of 20)
+
+struct SatLayout { int LD, plane; size_t bytes; };
+inline SatLayout sat_layout(int CG, int H, int W)
+{
+    SatLayout L;
+    L.LD = (W + 1) | 1;
+    L.plane = (H + 1) * L.LD;
+    L.bytes = (size_t)CG * L.plane * 8 + prefix_scratch_bytes(CG, H, W) + (size_t)RF_RC * GEO8;
+    return L;
+}
+
+template <int CG>
+__global__ void __launch_bounds__(RF_THREADS)
+k_roipool_fwd_sat(const float* __restrict__ fm, const uint32_t* __restrict__ geo8, float* __restrict__ out,
+                  int R, int C, int H, int W, int LD, int plane, int rois_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double* sat = reinterpret_cast<double*>(lds_raw);                // [CG][H+1][LD]
+    double* scr = sat + (size_t)CG * plane;                          // prefix scratch
+    uint32_t* geoL = reinterpret_cast<uint32_t*>(scr + prefix_scratch_doubles(CG, H, W));   // [RF_RC][8]
+    const int tid = threadIdx.x, HW = H * W;
+    const int c0 = blockIdx.x * CG;
+    const int r_lo = blockIdx.y * rois_per_wg, r_hi = r_lo + rois_per_wg < R ? r_lo + rois_per_wg : R;
+
+    // ---- load: sat[c][y+1][x+1] = FM, zero borders
+    for (int e = tid; e < CG * (H + 1); e += RF_THREADS) sat[(size_t)(e / (H + 1)) * plane + (e % (H + 1)) * LD] = 0.0;
+    for (int e = tid; e < CG * LD; e += RF_THREADS) sat[(size_t)(e / LD) * plane + e % LD] = 0.0;
+    for (int e = tid; e < CG * HW; e += RF_THREADS) {
+        const int c = e / HW, p = e - c * HW, y = p / W, x = p - y * W;
+        const float v = c0 + c < C ? fm[(size_t)(c0 + c) * HW + p] : 0.f;
+        sat[(size_t)c * plane + (y + 1) * LD + x + 1] = (double)v;
+    }
+    __syncthreads();
+    prefix2d(sat + LD + 1, scr, CG, H, W, LD, plane, tid, RF_THREADS);
+
+    // ---- outputs
+    constexpr int TPR = CG * KK, RPP = RF_ACTIVE / TPR;              // threads per RoI, RoIs per pass
+    const bool worker = tid < RF_ACTIVE;
+    const int rr0 = tid / TPR, q = tid - rr0 * TPR, c = q / KK, bin = q - c * KK, i = bin / KT, j = bin - i * KT;
+    const bool live = worker && c0 + c < C;
+    const double* S = sat + (size_t)c * plane;
+    const unsigned char* geoB = reinterpret_cast<const unsigned char*>(geoL) + 2 * i;
+    const int joff = 2 * KT + 2 * j - 2 * i;
+    for (int rb = r_lo; rb < r_hi; rb += RF_RC) {
+        const int rc = r_hi - rb < RF_RC ? r_hi - rb : RF_RC;
+        __syncthreads();                                             // previous records consumed
+        for (int e = tid; e < rc * (GEO8 / 4); e += RF_THREADS) geoL[e] = geo8[(size_t)rb * (GEO8 / 4) + e];
+        __syncthreads();
+        if (!live) continue;
+        float* dst = out + ((size_t)(rb + rr0) * C + c0) * KK + q;
+        const size_t dstep = (size_t)RPP * C * KK;
+        for (int rr = rr0; rr < rc; rr += RPP, dst += dstep) {
+            const unsigned char* gr = geoB + rr * GEO8;
+            const unsigned pi = *reinterpret_cast<const unsigned short*>(gr);
+            const unsigned pj = *reinterpret_cast<const unsigned short*>(gr + joff);
+            const int i0 = pi & 255, i1 = pi >> 8, j0 = pj & 255, j1 = pj >> 8;
+            double s = (S[i1 * LD + j1] - S[i0 * LD + j1]) - (S[i1 * LD + j0] - S[i0 * LD + j0]);
+            if (i1 <= i0 || j1 <= j0) s = 0.0;                       // the reference's loops do not run
+            const int n = (i1 - i0) * (j1 - j0);
+            float res = (float)s * __builtin_amdgcn_rcpf((float)n);  // n == 0: 0 * inf = NaN, as 0/0 in roipool_cuda.cu:61
+            if (n > 0 && !(__builtin_fabsf(res) <= 3.4028234663852886e38f)) {
+                // non-finite: an Inf / NaN anywhere above-left of the bin poisons the table.  Redo
+                // this bin in the reference's form (running f32 sum, row-major) from global memory.
+                const float* chp = fm + (size_t)(c0 + c) * HW;
+                float acc = 0.f;
+                for (int y = i0; y < i1; ++y)
+                    for (int x = j0; x < j1; ++x) acc += chp[y * W + x];
+                res = acc / (float)n;
+            }
+            *dst = res;
+        }
+    }
+}
+
+static int sat_cg(int C, int H, int W)
+{
+    for (int cg = 4; cg >= 1; cg >>= 1)
+        if (sat_layout(cg, H, W).bytes <= (size_t)LDS_MAX && (cg == 1 || C >= 2 * cg)) return cg;
+    return sat_layout(1, H, W).bytes <= (size_t)LDS_MAX ? 1 : 0;
 }
 
 bool roipool_fwd_supported(int R, int C, int H, int W, int k)
 {
-    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && (C + 63) / 64 <= 65535;
+    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && H <= 255 && W <= 255 && sat_cg(C, H, W) > 0;
 }
 
 size_t roipool_fwd_ws_bytes(int R, int C, int H, int W, int k)
 {
     if (!roipool_fwd_supported(R, C, H, W, k)) return 0;
-    return align256((size_t)C * H * W * sizeof(float)) + geo_bytes(R);
+    return geo8_bytes(R);
 }
 
 int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int,
                     void* ws, hipStream_t st)
 {
-    float* fmt = static_cast<float*>(ws);
-    int32_t* geo = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + align256((size_t)C * H * W * sizeof(float)));
-    int rc = transpose(fm, fmt, C, H * W, st);                       // (C, HW) -> (HW, C)
+    int rc = roi_geom8(rois, ws, R, H, W, st);
     if (rc != D2T_OK) return rc;
-    rc = roi_geom(rois, geo, nullptr, nullptr, R, H, W, st);
-    if (rc != D2T_OK) return rc;
-    hipLaunchKernelGGL(k_roipool_fwd_cl, dim3(R, (C + 63) / 64), dim3(RF_THREADS), 0, st, fmt, geo, out, C, W);
-    return launch_status();
-}
-
-constexpr int RB_LD = 65;                                            // accumulator row stride (floats): lanes along x read it conflict-free
-
-
-// batched (C x 49) -> (49 x C) transpose: block = one RoI x 64 channels
-__global__ void __launch_bounds__(256)
-k_transpose_gout(const float* __restrict__ in, float* __restrict__ out, int C)
-{
-    __shared__ float t[64 * KK + 8];
-    const int r = blockIdx.x, c0 = blockIdx.y * 64;
-    const int nch = C - c0 < 64 ? C - c0 : 64;
-    const float* src = in + ((size_t)r * C + c0) * KK;
-    for (int e = threadIdx.x; e < nch * KK; e += 256) t[e] = src[e];
-    __syncthreads();
-    float* dst = out + (size_t)r * KK * C + c0;
-    for (int e = threadIdx.x; e < KK * 64; e += 256) {
-        const int b = e >> 6, ch = e & 63;
-        if (ch < nch) dst[(size_t)b * C + ch] = t[ch * KK + b];
+    const int CG = sat_cg(C, H, W);
+    const SatLayout L = sat_layout(CG, H, W);
+    const int gx = (C + CG - 1) / CG;
+    int split = (256 + gx - 1) / gx;                                 // enough workgroups for every CU
+    const int max_split = (R + 63) / 64;
+    split = split < 1 ? 1 : (split > max_split ? max_split : split);
+    split = split > 65535 ? 65535 : split;
+    const int per = (R + split - 1) / split;
+    const dim3 grid(gx, (R + per - 1) / per);
+    const uint32_t* geo = static_cast<const uint32_t*>(ws);
+#define D2T_LAUNCH_SAT(CGV)                                                                              \
+    {                                                                                                    \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_roipool_fwd_sat<CGV>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX); \
+        (void)attr;                                                                                      \
+        hipLaunchKernelGGL(k_roipool_fwd_sat<CGV>, grid, dim3(RF_THREADS), L.bytes, st, fm, geo, out, R, C, H, W, \
+                           L.LD, L.plane, per);                                                          \
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// ROIPool backward, channel-last gather.  gt: gradOut transposed to (R, 49, C).
-// Workgroup = (map row y, 64 channels), one channel per lane; wave w walks RoIs [w*R/NW,
-// (w+1)*R/NW) and adds into its own LDS accumulator [W+1][65] (row W is a dummy); the partial rows
-// are added in a fixed order and stored as 64 rows of gradIn.  A first version walked the RoIs with
-// scalar loads and added pixel by pixel (269 us at config 3: a chain of latencies); this one:
-//  * work items (RoI r, bin row i containing y) come out of a row-mask table, 64 RoIs per
-//    instruction (lane = RoI): no scalar load per RoI;
-//  * RC_PF items are in flight: geometry record, 7 reciprocals and the 7 x 256 bytes of
-//    (transposed) gradOut are fetched RC_PF items ahead of their use;
-//  * 1/binNumel comes from a table written by k_roi_geom (one multiply instead of a divide per
-//    bin: <= 1 ulp from gradOut/n, the reference's atomics leave the order undefined anyway);
-//  * the pixels of the even column bins (disjoint when the RoI is >= 7 pixels wide) are read
-//    together, added, written together, then the odd bins: 2 LDS round trips per item instead of
-//    one per pixel (27 on average).  Slots past a bin's width go to the dummy row.
-// Per pixel the order is ascending (r, i, j) within a wave; the waves' rows are added in order.
-// ---------------------------------------------------------------------------------------
-constexpr int RC_PF = 4;                                             // work items in flight per wave
-
-__global__ void __launch_bounds__(256)
-k_roipool_bwd_batched(const float* __restrict__ gt, const int32_t* __restrict__ geo, const uint8_t* __restrict__ rowmask,
-                      const float* __restrict__ rcp, float* __restrict__ gin, int R, int C, int H, int W)
-{
-    extern __shared__ float lds[];                                   // [waves][W+1][65]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;
-    const int y = blockIdx.x, c0 = blockIdx.y * 64;
-    const int per = (W + 1) * RB_LD;
-    float* acc = lds + (size_t)wave * per + lane;
-    for (int x = 0; x <= W; ++x) acc[x * RB_LD] = 0.f;
-    const int cl = c0 + lane < C ? c0 + lane : C - 1;                // clamped lane channel (never stored)
-    const int r_lo = (int)((long long)R * wave / nw), r_hi = (int)((long long)R * (wave + 1) / nw);
-
-    // work-item generator; state is wave-uniform
-    int rb = r_lo - 64, cur = 0, mk = 0, bits = 0;
-    unsigned long long m = 0;
-    int nr = 0, ni = 0;
-    auto advance = [&]() -> bool {
-        for (;;) {
-            if (bits) {
-                ni = __builtin_ctz(bits);
-                bits &= bits - 1;
-                nr = rb + cur;
-                return true;
-            }
-            if (!m) {
-                if (rb + 64 >= r_hi) return false;
-                rb += 64;
-                mk = rb + lane < r_hi ? rowmask[(size_t)(rb + lane) * H + y] : 0;
-                m = __ballot(mk != 0);
-                continue;
-            }
-            cur = __builtin_ctzll(m);
-            m &= m - 1;
-            bits = __builtin_amdgcn_readlane(mk, cur);
-        }
-    };
-    struct Item { int rec; float rq; float v[KT]; };
-    auto fetch = [&](Item& it, int r, int i) {
-        it.rec = geo[(size_t)r * GEO + (lane & (GEO - 1))];          // the record, one int per lane
-        it.rq = rcp[(size_t)r * 64 + i * KT + (lane < KT ? lane : 0)];   // lanes 0..6: 1/n of the bin row's bins
-        const float* gr = gt + ((size_t)r * KK + i * KT) * C + cl;
-#pragma unroll
-        for (int j = 0; j < KT; ++j) it.v[j] = gr[(size_t)j * C];    // 7 coalesced loads
-    };
-    auto add_item = [&](const Item& it) {
-        int j0[KT], w[KT];
-        float q[KT];
-        int wmax = 0;
-        bool regular = true;
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            j0[j] = __builtin_amdgcn_readlane(it.rec, 2 * KT + j);
-            w[j] = __builtin_amdgcn_readlane(it.rec, 3 * KT + j) - j0[j];
-            wmax = w[j] > wmax ? w[j] : wmax;
-            q[j] = it.v[j] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, it.rq), j));
-        }
-#pragma unroll
-        for (int j = 0; j + 2 < KT; ++j) regular = regular && j0[j + 2] >= j0[j] + w[j];
-        auto batch = [&](auto sw_c, auto first_c) {                  // bins first, first+2, ..: SW slots each
-            constexpr int SW = decltype(sw_c)::value, FIRST = decltype(first_c)::value;
-            constexpr int NB = (KT - FIRST + 1) / 2;
-            float t[NB][SW];
-            int xo[NB][SW];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int s2 = 0; s2 < SW; ++s2) {
-                    const int j = FIRST + 2 * b;
-                    xo[b][s2] = (s2 < w[j] ? j0[j] + s2 : W) * RB_LD;   // wave-uniform; past the bin: dummy row
-                    t[b][s2] = acc[xo[b][s2]];
-                }
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int s2 = 0; s2 < SW; ++s2) acc[xo[b][s2]] = t[b][s2] + q[FIRST + 2 * b];
-        };
-        using std::integral_constant;
-        if (regular && wmax <= 4) {
-            batch(integral_constant<int, 4>{}, integral_constant<int, 0>{});
-            batch(integral_constant<int, 4>{}, integral_constant<int, 1>{});
-        } else if (regular && wmax <= 8) {
-            batch(integral_constant<int, 8>{}, integral_constant<int, 0>{});
-            batch(integral_constant<int, 8>{}, integral_constant<int, 1>{});
-        } else {                                                     // tiny or very wide RoIs: pixel by pixel
-#pragma unroll 1
-            for (int j = 0; j < KT; ++j)
-#pragma unroll 1
-                for (int x = j0[j]; x < j0[j] + w[j]; ++x) acc[x * RB_LD] += q[j];
-        }
-    };
-    Item it[RC_PF];
-    bool ok[RC_PF];
-#pragma unroll
-    for (int s = 0; s < RC_PF; ++s) {
-        ok[s] = advance();
-        if (ok[s]) fetch(it[s], nr, ni);
-    }
-    while (ok[0]) {                                                  // slots are consumed round-robin = in item order
-#pragma unroll
-        for (int s = 0; s < RC_PF; ++s) {
-            if (ok[s]) {
-                add_item(it[s]);
-                ok[s] = advance();
-                if (ok[s]) fetch(it[s], nr, ni);
-            }
-        }
-    }
-    __syncthreads();
-    // gin[c0+ch][y][0..W): lanes along x, fixed-order sum of the waves' partial rows
-    const int nch = C - c0 < 64 ? C - c0 : 64;
-    for (int e = threadIdx.x; e < nch * W; e += blockDim.x) {
-        const int ch = e / W, x = e - ch * W;
-        const int o = x * RB_LD + ch;
-        float a = lds[o];
-        for (int wv = 1; wv < nw; ++wv) a += lds[(size_t)wv * per + o];
-        gin[((size_t)(c0 + ch) * H + y) * W + x] = a;
-    }
-}
-
-bool roipool_bwd_supported(int R, int C, int H, int W, int k)
-{
-    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && (C + 63) / 64 <= 65535 &&
-           (size_t)(W + 1) * RB_LD * sizeof(float) <= 64 * 1024;
-}
-
-size_t roipool_bwd_ws_bytes(int R, int C, int H, int W, int k)
-{
-    if (!roipool_bwd_supported(R, C, H, W, k)) return 0;
-    return align256((size_t)R * C * KK * sizeof(float)) + geo_bytes(R) + align256((size_t)R * H) +
-           align256((size_t)R * 64 * sizeof(float));
-}
-
-int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int,
-                    void* ws, hipStream_t st)
-{
-    float* gt = static_cast<float*>(ws);
-    int32_t* geo = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + align256((size_t)R * C * KK * sizeof(float)));
-    hipLaunchKernelGGL(k_transpose_gout, dim3(R, (C + 63) / 64), dim3(256), 0, st, gout, gt, C);   // (R,C,49) -> (R,49,C)
-    int rc = launch_status();
-    if (rc != D2T_OK) return rc;
-    uint8_t* rowmask = reinterpret_cast<uint8_t*>(geo) + geo_bytes(R);
-    float* rcp = reinterpret_cast<float*>(rowmask + align256((size_t)R * H));
-    rc = roi_geom(rois, geo, rowmask, rcp, R, H, W, st);
-    if (rc != D2T_OK) return rc;
-    const dim3 grid(H, (C + 63) / 64);
-    const size_t acc_bytes = (size_t)(W + 1) * RB_LD * sizeof(float);
-    int waves = (int)(64 * 1024 / acc_bytes);                        // private accumulators that fit 64 KB of LDS
-    waves = waves > 4 ? 4 : waves;
-    hipLaunchKernelGGL(k_roipool_bwd_batched, grid, dim3(64 * waves), waves * acc_bytes, st,
-                       gt, geo, rowmask, rcp, gin, R, C, H, W);
+    if (CG == 4) D2T_LAUNCH_SAT(4) else if (CG == 2) D2T_LAUNCH_SAT(2) else D2T_LAUNCH_SAT(1)
+#undef D2T_LAUNCH_SAT
     return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
-// PSROIPool forward.  Workgroup = (RoI, 256 consecutive outputs (t, bin)).  The RoI's 49 cells
-// are evaluated once per workgroup (lanes 0..48, double-precision bin centres as the reference)
-// and shared through LDS instead of once per output; a thread then sums its cell row by row:
-// the pixels of a row are fetched with 8 independent (clamped) loads and added in ascending x, so
-// the dependent chain is the cell's rows, not its pixels.  The running sum sees the pixels in the
-// reference's order (ps_roipool_cuda.cu:60-66) and the guarded IEEE divide is kept: bit-identical.
+// PSROIPool cells, bin-major: cellsT[bin][r] = {i0, i1, j0, j1} (ps_roipool_cuda.cu:45-54), so that
+// 64 consecutive RoIs of one bin are one coalesced 1 KB load.
 // ---------------------------------------------------------------------------------------
+inline size_t cellsT_bytes(int R) { return align256((size_t)R * KK * sizeof(int4)); }
+
 __global__ void __launch_bounds__(256)
-k_psroipool_fwd_roi(const float* __restrict__ fm, const float* __restrict__ rois, float* __restrict__ out,
-                    int nT, int H, int W)
+k_ps_cells_T(const float* __restrict__ rois, int4* __restrict__ cellsT, int R, int H, int W)
 {
-    __shared__ int4 cells[KK];
-    const int r = blockIdx.x;
-    if (threadIdx.x < KK) {
-        const int i = threadIdx.x / KT, j = threadIdx.x - i * KT;
-        const Bounds c = psroi_cell<float>(rois + 4 * (size_t)r, i, j, H, W, KT);
-        cells[threadIdx.x] = make_int4(c.i0, c.i1, c.j0, c.j1);
+    const int r = blockIdx.x * 256 + threadIdx.x, bin = blockIdx.y;
+    if (r >= R) return;
+    const Bounds c = psroi_cell<float>(rois + 4 * (size_t)r, bin / KT, bin % KT, H, W, KT);
+    cellsT[(size_t)bin * R + r] = make_int4(c.i0, c.i1, c.j0, c.j1);
+}
+
+static int ps_cells_T(const float* rois, int4* cellsT, int R, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ps_cells_T, dim3((R + 255) / 256, KK), dim3(256), 0, st, rois, cellsT, R, H, W);
+    return launch_status();
+}
+
+// The output planes (t, bin) that read / feed input channel ch: (t+1)*bin == ch.  ch == 0: bin 0 of
+// every target (handled by the callers); otherwise bin | ch, 1 <= bin <= 48, ch / bin <= nT.
+// Lane b-1 of the first wave tests bin b; the list comes out in ascending bin order.
+__device__ __forceinline__ int ps_channel_planes(int ch, int nT, int* __restrict__ list /* LDS, 64 ints */, int tid)
+{
+    if (tid < 64) {
+        const int bin = tid + 1;
+        const bool is_src = ch > 0 && bin < KK && ch % bin == 0 && ch / bin <= nT;
+        const unsigned long long m = __ballot(is_src);
+        if (is_src) list[__builtin_popcountll(m & ((1ull << tid) - 1ull))] = (ch / bin - 1) * KK + bin;
+        if (tid == 0) list[63] = __builtin_popcountll(m);            // at most 48 entries: slot 63 is free
     }
     __syncthreads();
-    const int e = blockIdx.y * 256 + threadIdx.x;                    // output (t, bin) of this RoI
-    if (e >= nT * KK) return;
-    const int t = e / KK, bin = e - t * KK;
-    const int4 c = cells[bin];
-    const float* ch = fm + (size_t)((t + 1) * bin) * H * W;          // ps_roipool_cuda.cu:58
-    const int w = c.w - c.z;
-    float acc = 0.f;
-    for (int y = c.x; y < c.y; ++y) {
-        const float* row = ch + y * W + c.z;
-        for (int x0 = 0; x0 < w; x0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = row[x0 + k < w ? x0 + k : w - 1];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (x0 + k < w) acc += v[k];                         // ascending x
-        }
-    }
-    const int n = (c.y - c.x) * w;
-    if (n > 0) acc /= static_cast<float>(n);                         // guarded divide, :68
-    out[(size_t)r * nT * KK + e] = acc;
+    return list[63];
 }
+
+// ---------------------------------------------------------------------------------------
+// PSROIPool forward.  Workgroup = (input channel, chunk of RoIs), 256 threads.  The channel is
+// staged in LDS once; an item is (plane p of the channel, RoI r), lane = RoI.  Each item keeps the
+// reference's running sum over its cell in row-major order and its guarded IEEE divide:
+// bit-identical.  tmpT[(t*49+bin)][r] is transposed to out[r][t][bin] by the caller.
+// ---------------------------------------------------------------------------------------
+constexpr int PF_RC = 1024;                   // RoIs per workgroup
+
+__global__ void __launch_bounds__(256)
+k_psroipool_fwd_chan(const float* __restrict__ fm, const int4* __restrict__ cellsT, float* __restrict__ tmpT,
+                     int R, int nT, int H, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, HW = H * W;
+    float* map = reinterpret_cast<float*>(lds_raw);                  // [H*W]
+    int* list = reinterpret_cast<int*>(lds_raw + (((size_t)HW * 4 + 15) & ~(size_t)15));   // [64]
+    // blockIdx.x < nT: channel 0, target t = blockIdx.x alone (bin 0 of EVERY target reads channel 0:
+    // one workgroup per target instead of one for all nT of them); otherwise channel blockIdx.x - nT + 1
+    const int ch = blockIdx.x < nT ? 0 : blockIdx.x - nT + 1;
+    const int r_lo = blockIdx.y * PF_RC, nr = R - r_lo < PF_RC ? R - r_lo : PF_RC;
+    const int np = ch == 0 ? 1 : ps_channel_planes(ch, nT, list, tid);
+    if (np == 0) return;                                             // no output reads this channel
+    const float* src = fm + (size_t)ch * HW;
+    for (int e = tid; e < HW; e += 256) map[e] = src[e];
+    __syncthreads();
+    const int items = np * nr;
+    for (int e = tid; e < items; e += 256) {
+        const int p = e / nr, r = r_lo + (e - p * nr);
+        const int pl = ch == 0 ? (int)blockIdx.x * KK : list[p];     // plane index t*49 + bin
+        const int bin = pl % KK;
+        const int4 c = cellsT[(size_t)bin * R + r];
+        float acc = 0.f;
+        for (int y = c.x; y < c.y; ++y) {
+            const float* row = map + y * W;
+            for (int x0 = c.z; x0 < c.w; x0 += 4) {                  // 4 independent LDS loads, then the
+                float v[4];                                          // adds in ascending x (:60-66)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = row[x0 + k < c.w ? x0 + k : c.w - 1];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x0 + k < c.w) acc += v[k];
+            }
+        }
+        const int n = (c.y - c.x) * (c.w - c.z);
+        if (n > 0) acc /= static_cast<float>(n);                     // guarded divide, :67-69
+        tmpT[(size_t)pl * R + r] = acc;
+    }
+}
+
+// Below this many (RoI, target) pairs the whole op is launch-bound and the single-launch
+// thread-per-output kernel (d2t_pool_bwd.hip) is the faster one (R=300: 14-18 us against 25-29 us);
+// above it the channel-resident kernel wins (R=3000, nT=31: 91 us against 129 us).
+static bool ps_fwd_small(int R, int nT) { return 1LL * R * nT < 40000; }
 
 bool psroipool_fwd_supported(int R, int nT, int H, int W, int k)
 {
-    return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && (nT * KK + 255) / 256 <= 65535;
+    return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && (size_t)H * W * 4 <= (size_t)LDS_MAX - 1024 && H <= 32767 && W <= 32767 &&
+           (R + PF_RC - 1) / PF_RC <= 65535 && 1LL * nT * KK * R < 0x7fffffffLL && (nT * KK + 255) / 256 <= 65535;
 }
 
-int psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int,
-                      hipStream_t st)
+size_t psroipool_fwd_ws_bytes(int R, int nT, int H, int W, int k)
 {
-    hipLaunchKernelGGL(k_psroipool_fwd_roi, dim3(R, (nT * KK + 255) / 256), dim3(256), 0, st, fm, rois, out, nT, H, W);
-    return launch_status();
+    if (!psroipool_fwd_supported(R, nT, H, W, k) || ps_fwd_small(R, nT)) return 0;
+    return cellsT_bytes(R) + align256((size_t)nT * KK * R * sizeof(float));
 }
 
-// ---------------------------------------------------------------------------------------
-// Pixel ownership of the PSROIPool backward: 4 waves x bands of <= PX_ROWS rows, lane = column
-// (two column groups for maps wider than 64).
-// ---------------------------------------------------------------------------------------
-constexpr int PX_MAXROWS = 16;               // rows per wave band: H <= 64
-constexpr int PX_XG = 2;                     // column groups: W <= 128
-
-// ---------------------------------------------------------------------------------------
-// PSROIPool backward, phase 1.  Workgroup = output plane (t, bin).  cells: (R,7,7,4) int32.
-// part[plane][y][x] = sum over RoIs r whose cell `bin` contains (y,x) of gout[r,t,bin] / n
-// (ps_roipool_cuda.cu:131-139), ascending r.
-// ---------------------------------------------------------------------------------------
-template <int PX_ROWS>                       // band height the row loop is unrolled for (10: H <= 40)
-__global__ void __launch_bounds__(256)
-k_psroipool_bwd_plane(const float* __restrict__ gout, const int32_t* __restrict__ cells, float* __restrict__ part,
-                      int R, int nT, int H, int W)
-{
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int plane = blockIdx.x, bin = plane % KK;                  // plane = t*49 + bin
-    const int band = (H + 3) >> 2;
-    const int y_lo = wave * band, y_hi = y_lo + band < H ? y_lo + band : H;
-    float acc[PX_ROWS][PX_XG];
-#pragma unroll
-    for (int k = 0; k < PX_ROWS; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; }
-
-    if (y_lo < y_hi) {
-        const int4* ct = reinterpret_cast<const int4*>(cells) + bin;
-        const float* gp = gout + plane;
-        for (int rb = 0; rb < R; rb += 64) {
-            // 64 RoIs per instruction: lane l fetches and tests RoI rb+l
-            const int rr = rb + lane;
-            int4 cb = make_int4(0, 0, 0, 0);
-            float v = 0.f;
-            if (rr < R) {
-                cb = ct[(size_t)rr * KK];
-                v = gp[(size_t)rr * nT * KK];
-            }
-            const int n = (cb.y - cb.x) * (cb.w - cb.z);
-            const bool hit = cb.y > cb.x && cb.w > cb.z && cb.y > y_lo && cb.x < y_hi;
-            v = v / static_cast<float>(n > 0 ? n : 1);               // ps_roipool_cuda.cu:135
-            unsigned long long m = __ballot(hit);
-            while (m) {                                              // ascending r
-                const int l = __builtin_ctzll(m);
-                m &= m - 1;
-                const int i0 = __builtin_amdgcn_readlane(cb.x, l), i1 = __builtin_amdgcn_readlane(cb.y, l);
-                const int j0 = __builtin_amdgcn_readlane(cb.z, l), j1 = __builtin_amdgcn_readlane(cb.w, l);
-                const float vv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-                const float v0 = (lane >= j0 && lane < j1) ? vv : 0.f;
-                const float v1 = (lane + 64 >= j0 && lane + 64 < j1) ? vv : 0.f;
-#pragma unroll
-                for (int k = 0; k < PX_ROWS; ++k) {
-                    const int y = y_lo + k;
-                    if (y >= i0 && y < i1 && y < y_hi) { acc[k][0] += v0; acc[k][1] += v1; }   // wave-uniform
-                }
-            }
-        }
-    }
-    float* dst = part + (size_t)plane * H * W;
-#pragma unroll
-    for (int k = 0; k < PX_ROWS; ++k) {
-        const int y = y_lo + k;
-        if (y < y_hi) {
-            if (lane < W) dst[y * W + lane] = acc[k][0];
-            if (lane + 64 < W) dst[y * W + lane + 64] = acc[k][1];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// PSROIPool backward, phase 1, LDS form (maps up to 4096 pixels).  Workgroup = output plane
-// (t, bin); each of the 4 waves owns a quarter of the RoIs and a PRIVATE copy of the plane in LDS.
-// 64 RoIs are fetched per instruction (lane = RoI) and their cells computed on the fly (no cell
-// table, no extra launch).  Two ways to add them, chosen by the launcher:
-//   SWEEP = false  every non-empty cell in turn (ascending r) by the lanes of an 8 x 8 grid laid
-//                  over it: one LDS read-add-write of <= 64 pixels, ~25 instructions per cell (the
-//                  register-band form above needs ~80: it tests all of its rows against every cell);
-//   SWEEP = true   all 64 cells together, pixel (dy, dx) of every cell per step, with ds_add_f32
-//                  on the wave-private plane: ~5 instructions per cell but ~3.4 cycles per lane in
-//                  the LDS -- wins when there are too few planes to hide the per-cell latency.
-// Each wave adds its RoIs in ascending order, the four copies are summed in wave order.
-// ---------------------------------------------------------------------------------------
-constexpr int PL_WAVES = 4;
-constexpr int PL_MAXPIX = 4096;                                      // 4 planes x 16 KB = 64 KB of LDS
-
-template <bool SWEEP>
-__global__ void __launch_bounds__(PL_WAVES * 64)
-k_psroipool_bwd_plane_lds(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ part,
-                          int R, int nT, int H, int W)
-{
-    extern __shared__ float planes[];                                // [PL_WAVES][H*W]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int plane = blockIdx.x, bin = plane % KK, HW = H * W;      // plane = t*49 + bin
-    float* mine = planes + wave * HW;
-    for (int e = lane; e < HW; e += 64) mine[e] = 0.f;
-    const int dy = lane >> 3, dx = lane & 7, loff = dy * W + dx;
-    const int r_lo = (int)((long long)R * wave / PL_WAVES), r_hi = (int)((long long)R * (wave + 1) / PL_WAVES);
-    const int bi = bin / KT, bj = bin - bi * KT;
-    const float* gp = gout + plane;
-    for (int rb = r_lo; rb < r_hi; rb += 64) {
-        const int rr = rb + lane;
-        int4 cb = make_int4(0, 0, 0, 0);                             // (i0, i1, j0, j1) of this RoI's cell
-        float v = 0.f;
-        if (rr < r_hi) {
-            const Bounds c = psroi_cell<float>(rois + 4 * (size_t)rr, bi, bj, H, W, KT);
-            cb = make_int4(c.i0, c.i1, c.j0, c.j1);
-            v = gp[(size_t)rr * nT * KK];
-        }
-        const int n = (cb.y - cb.x) * (cb.w - cb.z);
-        const bool hit = cb.y > cb.x && cb.w > cb.z;
-        v = v / static_cast<float>(n > 0 ? n : 1);                   // ps_roipool_cuda.cu:135
-        if (SWEEP) {
-            // lane = RoI: the 64 cells are swept together, pixel (dy, dx) of every cell per step, with
-            // LDS float adds (the plane is private to the wave: no contention, fixed order)
-            const int h = hit ? cb.y - cb.x : 0, w = cb.w - cb.z;
-            float* p = mine + cb.x * W + cb.z;
-            for (int sy = 0; __ballot(sy < h); ++sy)
-                for (int sx = 0; __ballot(sy < h && sx < w); ++sx)
-                    if (sy < h && sx < w)
-                        __hip_atomic_fetch_add(p + sy * W + sx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            continue;
-        }
-        // cells are visited one at a time in ascending r; the lanes form an 8 x 8 grid laid over the
-        // cell: one LDS read-add-write covers it (larger cells take more grid positions)
-        const int base = cb.x * W + cb.z;
-        const int hw = ((cb.y - cb.x) << 16) | (cb.w - cb.z);
-        unsigned long long m = __ballot(hit);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const int sb = __builtin_amdgcn_readlane(base, l), shw = __builtin_amdgcn_readlane(hw, l);
-            const float vv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-            const int h = shw >> 16, w = shw & 0xffff;
-            float* p = mine + sb + loff;
-            if (h <= 8 && w <= 8) {                                  // wave-uniform: the usual case
-                if (dy < h && dx < w) *p += vv;
-            } else {
-                for (int ty = 0; ty < h; ty += 8)
-                    for (int tx = 0; tx < w; tx += 8)
-                        if (ty + dy < h && tx + dx < w) p[ty * W + tx] += vv;
-            }
-        }
-    }
-    __syncthreads();
-    float* dst = part + (size_t)plane * HW;
-    for (int e = threadIdx.x; e < HW; e += PL_WAVES * 64)
-        dst[e] = ((planes[e] + planes[HW + e]) + planes[2 * HW + e]) + planes[3 * HW + e];
-}
-
-// Phase 2: the planes that map to an input channel are (t, bin) with (t+1)*bin == ch, i.e. bin | ch
-// with ch/bin <= nT (ps_roipool_cuda.cu:58); channel 0 collects bin 0 of every t.  Each workgroup
-// finds its channel's planes itself (ascending bin) and adds them in that fixed order.
-
-// phase 2: gin[ch] = sum of the planes that map to ch, ascending bin then t; channels nothing
-// maps to are zero.
-__global__ void __launch_bounds__(256)
-k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, int nT, int HW)
-{
-    // planes (t, bin) with (t+1)*bin == ch, ascending bin: lane b-1 of the first wave tests bin b
-    __shared__ int32_t srcs[KK];
-    __shared__ int nsrc;
-    const int ch = blockIdx.y;
-    if (threadIdx.x < 64) {
-        const int bin = threadIdx.x + 1;
-        const bool is_src = ch > 0 && bin < KK && ch % bin == 0 && ch / bin <= nT;
-        const unsigned long long m = __ballot(is_src);
-        if (is_src) srcs[__builtin_popcountll(m & ((1ull << threadIdx.x) - 1ull))] = (ch / bin - 1) * KK + bin;
-        if (threadIdx.x == 0) nsrc = __builtin_popcountll(m);
-    }
-    __syncthreads();
-    const int ns = nsrc;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
-        float a = 0.f;
-        if (ch == 0) {                                               // bin 0 of every target
-            for (int t = 0; t < nT; ++t) a += part[(size_t)(t * KK) * HW + p];
-        } else {
-            for (int k = 0; k < ns; ++k) a += part[(size_t)srcs[k] * HW + p];
-        }
-        gin[(size_t)ch * HW + p] = a;
-    }
-}
-
-bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
-{
-    return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && H <= 4 * PX_MAXROWS && W <= 64 * PX_XG && nT * KK <= 65535;
-}
-
-size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
-{
-    if (!psroipool_bwd_supported(R, nT, H, W, k)) return 0;
-    return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float));
-}
-
-int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
+int psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int k,
                       void* ws, hipStream_t st)
 {
-    int32_t* cells = static_cast<int32_t*>(ws);                      // only the register-band form reads a cell table
-    float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + bins_bytes(R));
-    int rc;
-    if (H * W <= PL_MAXPIX) {
-        // few planes (< 2 workgroups per CU): one wave per SIMD, latency-bound -> sweep 64 cells at a time;
-        // many planes: the LDS float-add rate (~3.4 cycles per lane) would bound -> per-cell read-add-write
-        if (nT * KK < 512)
-            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<true>, dim3(nT * KK), dim3(PL_WAVES * 64),
-                               (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
-        else
-            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<false>, dim3(nT * KK), dim3(PL_WAVES * 64),
-                               (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
-    } else {
-        rc = psroipool_bins<float>(rois, cells, R, H, W, k, st);
-        if (rc != D2T_OK) return rc;
-        if (H <= 40)
-            hipLaunchKernelGGL(k_psroipool_bwd_plane<10>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
-        else
-            hipLaunchKernelGGL(k_psroipool_bwd_plane<PX_MAXROWS>, dim3(nT * KK), dim3(256), 0, st, gout, cells, part, R, nT, H, W);
-    }
+    if (ps_fwd_small(R, nT)) return psroipool_fwd_small_f32(fm, rois, out, R, nT, H, W, k, st);
+    int4* cellsT = static_cast<int4*>(ws);
+    float* tmpT = reinterpret_cast<float*>(static_cast<char*>(ws) + cellsT_bytes(R));
+    int rc = ps_cells_T(rois, cellsT, R, H, W, st);
+    if (rc != D2T_OK) return rc;
+    const size_t lds = (((size_t)H * W * 4 + 15) & ~(size_t)15) + 256;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_psroipool_fwd_chan),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    (void)attr;
+    hipLaunchKernelGGL(k_psroipool_fwd_chan, dim3(nT * KK + nT - 1, (R + PF_RC - 1) / PF_RC), dim3(256), lds, st,
+                       fm, cellsT, tmpT, R, nT, H, W);
     rc = launch_status();
     if (rc != D2T_OK) return rc;
-    const int HW = H * W;
-    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
-    return launch_status();
+    return transpose(tmpT, out, nT * KK, R, st);                     // (t*49+bin, r) -> (r, t*49+bin)
 }
 
 }}  // namespace d2t::tuned

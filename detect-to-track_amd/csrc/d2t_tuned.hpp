@@ -30,8 +30,11 @@ int    roipool_bwd_f32(const float* gout, const float* rois, float* gin,
                        int R, int C, int H, int W, int k, void* ws, hipStream_t st);
 
 bool   psroipool_fwd_supported(int R, int nT, int H, int W, int k);
+size_t psroipool_fwd_ws_bytes(int R, int nT, int H, int W, int k);
 int    psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int k,
-                         hipStream_t st);
+                         void* ws, hipStream_t st);
+int    psroipool_fwd_small_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int k,
+                               hipStream_t st);
 bool   psroipool_bwd_supported(int R, int nT, int H, int W, int k);
 size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k);
 int    psroipool_bwd_f32(const float* gout, const float* rois, float* gin,

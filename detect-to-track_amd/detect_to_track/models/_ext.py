@@ -165,8 +165,9 @@ def ps_roipool_forward(FM: Tensor, rois: Tensor, n_targets: int, r_hw: int, impl
     _, H, W = FM.shape
     with torch.cuda.device(FM.device):
         out = torch.empty((R, n_targets, r_hw, r_hw), dtype=FM.dtype, device=FM.device)
+        ws, n = _workspace(_native.lib.d2t_psroipool_fwd_workspace_bytes(R, n_targets, H, W, r_hw, FM.element_size()), FM)
         rc = getattr(_native.lib, f"d2t_psroipool_fwd_{sfx}")(
-            FM.data_ptr(), rois.data_ptr(), out.data_ptr(), R, n_targets, H, W, r_hw, 0, 0, impl, _stream(FM))
+            FM.data_ptr(), rois.data_ptr(), out.data_ptr(), R, n_targets, H, W, r_hw, _ptr(ws), n, impl, _stream(FM))
     _native.check(rc, "ps_roipool_forward")
     return out
 
