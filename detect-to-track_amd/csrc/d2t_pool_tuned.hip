@@ -68,37 +68,13 @@ static int transpose(const float* in, float* out, int rows, int cols, hipStream_
 }
 
 // ---------------------------------------------------------------------------------------
-// ROIPool geometry: per RoI 32 bytes = {(i0,i1)[7], (j0,j1)[7], 4 pad}: byte 2i = i0 of bin row i,
-// 2i+1 = its i1, byte 14+2j = j0 of bin column j, 15+2j = its j1 (one 16-bit load per axis).  Row
-// bounds of a bin depend on i only, column bounds on j only (roipool_cuda.cu:41-50), so 28 numbers
-// describe all 49 bins; every bound lies in [0, 255] (maps above 255 rows or columns take the generic
-// kernels).
+// ROIPool geometry record (LDS): per RoI 32 bytes = {(i0,i1)[7], (j0,j1)[7], 4 pad}: byte 2i = i0 of
+// bin row i, 2i+1 = its i1, byte 14+2j = j0 of bin column j, 15+2j = its j1 (one 16-bit load per
+// axis).  Row bounds of a bin depend on i only, column bounds on j only (roipool_cuda.cu:41-50), so
+// 28 numbers describe all 49 bins; every bound lies in [0, 255] (maps above 255 rows or columns take
+// the generic kernels).
 // ---------------------------------------------------------------------------------------
 constexpr int GEO8 = 32;
-inline size_t geo8_bytes(int R) { return align256((size_t)R * GEO8); }
-
-__global__ void __launch_bounds__(64)
-k_roi_geom8(const float* __restrict__ rois, uint32_t* __restrict__ geo8, int R, int H, int W)
-{
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= R) return;
-    uint32_t w[GEO8 / 4] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto put = [&](int k, int v) { w[k >> 2] |= (uint32_t)(v & 255) << (8 * (k & 3)); };
-#pragma unroll
-    for (int q = 0; q < KT; ++q) {
-        const Bounds b = roi_bin<float>(rois + 4 * (size_t)r, q, q, H, W, KT);   // (q, q): row bounds of i = q, column bounds of j = q
-        put(2 * q, b.i0); put(2 * q + 1, b.i1); put(2 * KT + 2 * q, b.j0); put(2 * KT + 2 * q + 1, b.j1);
-    }
-#pragma unroll
-    for (int k = 0; k < GEO8 / 4; ++k) geo8[(size_t)r * (GEO8 / 4) + k] = w[k];
-}
-
-static int roi_geom8(const float* rois, void* geo8, int R, int H, int W, hipStream_t st)
-{
-    if (R == 0) return D2T_OK;
-    hipLaunchKernelGGL(k_roi_geom8, dim3((R + 63) / 64), dim3(64), 0, st, rois, static_cast<uint32_t*>(geo8), R, H, W);
-    return launch_status();
-}
 
 // ---------------------------------------------------------------------------------------
 // In-place inclusive 2-D prefix sum of nb f64 maps F[b][H][LDW] (columns 0..W-1), all threads of the
@@ -120,47 +96,52 @@ __device__ __forceinline__ void prefix2d(double* __restrict__ F, double* __restr
 {
     const int nsx = (W + PX_SEG - 1) / PX_SEG, nsy = (H + PY_SEG - 1) / PY_SEG;
     const int ntx = nb * H * nsx;
-    for (int t = tid; t < ntx; t += nthr) {
-        const int row = t / nsx, sg = t - row * nsx, bb = row / H, y = row - bb * H;
-        double* p = F + (size_t)bb * mstride + y * LDW;
-        const int x0 = sg * PX_SEG, x1 = x0 + PX_SEG < W ? x0 + PX_SEG : W;
-        double run = 0.0;
-        for (int x = x0; x < x1; ++x) { run += p[x]; p[x] = run; }
-        scr[t] = run;
-    }
-    __syncthreads();
-    for (int t = tid; t < ntx; t += nthr) {
-        const int row = t / nsx, sg = t - row * nsx;
-        if (sg == 0) continue;
+    // along x: a thread reads its segment into registers (independent loads: one LDS round trip),
+    // prefixes it there, publishes the segment total, and after the barrier writes segment + the
+    // totals of the segments to its left.  All threads run the same number of iterations.
+    for (int t0 = 0; t0 < ntx; t0 += nthr) {
+        const int t = t0 + tid;
+        const bool on = t < ntx;
+        const int row = on ? t / nsx : 0, sg = on ? t - row * nsx : 0, bb = row / H, y = row - bb * H;
+        double* p = F + (size_t)bb * mstride + y * LDW + sg * PX_SEG;
+        const int len = W - sg * PX_SEG < PX_SEG ? W - sg * PX_SEG : PX_SEG;
+        double v[PX_SEG];
+#pragma unroll
+        for (int k = 0; k < PX_SEG; ++k) v[k] = on && k < len ? p[k] : 0.0;
+#pragma unroll
+        for (int k = 1; k < PX_SEG; ++k) v[k] += v[k - 1];
+        if (on) scr[t] = v[PX_SEG - 1];
+        __syncthreads();
         double off = 0.0;
         for (int s2 = 0; s2 < sg; ++s2) off += scr[row * nsx + s2];
-        const int bb = row / H, y = row - bb * H;
-        double* p = F + (size_t)bb * mstride + y * LDW;
-        const int x0 = sg * PX_SEG, x1 = x0 + PX_SEG < W ? x0 + PX_SEG : W;
-        for (int x = x0; x < x1; ++x) p[x] += off;
+#pragma unroll
+        for (int k = 0; k < PX_SEG; ++k)
+            if (on && k < len) p[k] = v[k] + off;
+        __syncthreads();
     }
-    __syncthreads();
+    // along y the same way; consecutive threads own consecutive columns
     double* scy = scr + ntx;
     const int nty = nb * nsy * W;
-    for (int t = tid; t < nty; t += nthr) {
-        const int bs = t / W, x = t - bs * W, bb = bs / nsy, sg = bs - bb * nsy;   // consecutive threads: consecutive columns
-        double* p = F + (size_t)bb * mstride + x;
-        const int y0 = sg * PY_SEG, y1 = y0 + PY_SEG < H ? y0 + PY_SEG : H;
-        double run = 0.0;
-        for (int y = y0; y < y1; ++y) { run += p[y * LDW]; p[y * LDW] = run; }
-        scy[t] = run;
-    }
-    __syncthreads();
-    for (int t = tid; t < nty; t += nthr) {
-        const int bs = t / W, x = t - bs * W, bb = bs / nsy, sg = bs - bb * nsy;
-        if (sg == 0) continue;
+    for (int t0 = 0; t0 < nty; t0 += nthr) {
+        const int t = t0 + tid;
+        const bool on = t < nty;
+        const int bs = on ? t / W : 0, x = on ? t - bs * W : 0, bb = bs / nsy, sg = bs - bb * nsy;
+        double* p = F + (size_t)bb * mstride + (size_t)sg * PY_SEG * LDW + x;
+        const int len = H - sg * PY_SEG < PY_SEG ? H - sg * PY_SEG : PY_SEG;
+        double v[PY_SEG];
+#pragma unroll
+        for (int k = 0; k < PY_SEG; ++k) v[k] = on && k < len ? p[k * LDW] : 0.0;
+#pragma unroll
+        for (int k = 1; k < PY_SEG; ++k) v[k] += v[k - 1];
+        if (on) scy[t] = v[PY_SEG - 1];
+        __syncthreads();
         double off = 0.0;
         for (int s2 = 0; s2 < sg; ++s2) off += scy[(bb * nsy + s2) * W + x];
-        double* p = F + (size_t)bb * mstride + x;
-        const int y0 = sg * PY_SEG, y1 = y0 + PY_SEG < H ? y0 + PY_SEG : H;
-        for (int y = y0; y < y1; ++y) p[y * LDW] += off;
+#pragma unroll
+        for (int k = 0; k < PY_SEG; ++k)
+            if (on && k < len) p[k * LDW] = v[k] + off;
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -191,7 +172,7 @@ inline SatLayout sat_layout(int CG, int H, int W)
 
 template <int CG>
 __global__ void __launch_bounds__(RF_THREADS)
-k_roipool_fwd_sat(const float* __restrict__ fm, const uint32_t* __restrict__ geo8, float* __restrict__ out,
+k_roipool_fwd_sat(const float* __restrict__ fm, const float* __restrict__ rois, float* __restrict__ out,
                   int R, int C, int H, int W, int LD, int plane, int rois_per_wg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -202,13 +183,31 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const uint32_t* __restrict__ geo
     const int c0 = blockIdx.x * CG;
     const int r_lo = blockIdx.y * rois_per_wg, r_hi = r_lo + rois_per_wg < R ? r_lo + rois_per_wg : R;
 
-    // ---- load: sat[c][y+1][x+1] = FM, zero borders
+    // ---- load: sat[c][y+1][x+1] = FM, zero borders.  The CG channels are one contiguous run of
+    // CG*H*W floats; every thread issues its (up to 4 x n) loads before the first use.
     for (int e = tid; e < CG * (H + 1); e += RF_THREADS) sat[(size_t)(e / (H + 1)) * plane + (e % (H + 1)) * LD] = 0.0;
     for (int e = tid; e < CG * LD; e += RF_THREADS) sat[(size_t)(e / LD) * plane + e % LD] = 0.0;
-    for (int e = tid; e < CG * HW; e += RF_THREADS) {
-        const int c = e / HW, p = e - c * HW, y = p / W, x = p - y * W;
-        const float v = c0 + c < C ? fm[(size_t)(c0 + c) * HW + p] : 0.f;
-        sat[(size_t)c * plane + (y + 1) * LD + x + 1] = (double)v;
+    {
+        // a wave takes map rows (one coalesced run each), four rows' loads in flight; no per-element
+        // index arithmetic
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nrow = CG * H;
+        constexpr int NWV = RF_THREADS / 64;
+        for (int row0 = wave; row0 < nrow; row0 += 4 * NWV) {
+            for (int xb = 0; xb < W; xb += 64) {
+                const int x = xb + lane;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = row0 + k * NWV, c = row / H, y = row - c * H;
+                    v[k] = row < nrow && x < W && c0 + c < C ? fm[(size_t)(c0 + c) * HW + y * W + x] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = row0 + k * NWV, c = row / H, y = row - c * H;
+                    if (row < nrow && x < W) sat[(size_t)c * plane + (y + 1) * LD + x + 1] = (double)v[k];
+                }
+            }
+        }
     }
     __syncthreads();
     prefix2d(sat + LD + 1, scr, CG, H, W, LD, plane, tid, RF_THREADS);
@@ -224,13 +223,20 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const uint32_t* __restrict__ geo
     for (int rb = r_lo; rb < r_hi; rb += RF_RC) {
         const int rc = r_hi - rb < RF_RC ? r_hi - rb : RF_RC;
         __syncthreads();                                             // previous records consumed
-        for (int e = tid; e < rc * (GEO8 / 4); e += RF_THREADS) geoL[e] = geo8[(size_t)rb * (GEO8 / 4) + e];
+        unsigned char* geoW = reinterpret_cast<unsigned char*>(geoL);
+        for (int e = tid; e < rc * KT; e += RF_THREADS) {            // bin row q and bin column q of RoI rb + e/7
+            const int rr = e / KT, qq = e - rr * KT;
+            const Bounds bq = roi_bin<float>(rois + 4 * (size_t)(rb + rr), qq, qq, H, W, KT);
+            *reinterpret_cast<unsigned short*>(geoW + rr * GEO8 + 2 * qq) = (unsigned short)(bq.i0 | (bq.i1 << 8));
+            *reinterpret_cast<unsigned short*>(geoW + rr * GEO8 + 2 * KT + 2 * qq) = (unsigned short)(bq.j0 | (bq.j1 << 8));
+        }
         __syncthreads();
         if (!live) continue;
         float* dst = out + ((size_t)(rb + rr0) * C + c0) * KK + q;
         const size_t dstep = (size_t)RPP * C * KK;
-        for (int rr = rr0; rr < rc; rr += RPP, dst += dstep) {
-            const unsigned char* gr = geoB + rr * GEO8;
+        // two RoIs per iteration: two independent chains of LDS round trips per thread
+        auto pool = [&](int rr, float* d, bool on) {
+            const unsigned char* gr = geoB + (on ? rr : rr0) * GEO8;
             const unsigned pi = *reinterpret_cast<const unsigned short*>(gr);
             const unsigned pj = *reinterpret_cast<const unsigned short*>(gr + joff);
             const int i0 = pi & 255, i1 = pi >> 8, j0 = pj & 255, j1 = pj >> 8;
@@ -238,7 +244,7 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const uint32_t* __restrict__ geo
             if (i1 <= i0 || j1 <= j0) s = 0.0;                       // the reference's loops do not run
             const int n = (i1 - i0) * (j1 - j0);
             float res = (float)s * __builtin_amdgcn_rcpf((float)n);  // n == 0: 0 * inf = NaN, as 0/0 in roipool_cuda.cu:61
-            if (n > 0 && !(__builtin_fabsf(res) <= 3.4028234663852886e38f)) {
+            if (on && n > 0 && !(__builtin_fabsf(res) <= 3.4028234663852886e38f)) {
                 // non-finite: an Inf / NaN anywhere above-left of the bin poisons the table.  Redo
                 // this bin in the reference's form (running f32 sum, row-major) from global memory.
                 const float* chp = fm + (size_t)(c0 + c) * HW;
@@ -247,7 +253,11 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const uint32_t* __restrict__ geo
                     for (int x = j0; x < j1; ++x) acc += chp[y * W + x];
                 res = acc / (float)n;
             }
-            *dst = res;
+            if (on) *d = res;
+        };
+        for (int rr = rr0; rr < rc; rr += 2 * RPP, dst += 2 * dstep) {
+            pool(rr, dst, true);
+            pool(rr + RPP, dst + dstep, rr + RPP < rc);
         }
     }
 }
@@ -264,17 +274,11 @@ bool roipool_fwd_supported(int R, int C, int H, int W, int k)
     return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && H <= 255 && W <= 255 && sat_cg(C, H, W) > 0;
 }
 
-size_t roipool_fwd_ws_bytes(int R, int C, int H, int W, int k)
-{
-    if (!roipool_fwd_supported(R, C, H, W, k)) return 0;
-    return geo8_bytes(R);
-}
+size_t roipool_fwd_ws_bytes(int, int, int, int, int) { return 0; }
 
 int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int,
-                    void* ws, hipStream_t st)
+                    void*, hipStream_t st)
 {
-    int rc = roi_geom8(rois, ws, R, H, W, st);
-    if (rc != D2T_OK) return rc;
     const int CG = sat_cg(C, H, W);
     const SatLayout L = sat_layout(CG, H, W);
     const int gx = (C + CG - 1) / CG;
@@ -284,13 +288,12 @@ int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C
     split = split > 65535 ? 65535 : split;
     const int per = (R + split - 1) / split;
     const dim3 grid(gx, (R + per - 1) / per);
-    const uint32_t* geo = static_cast<const uint32_t*>(ws);
 #define D2T_LAUNCH_SAT(CGV)                                                                              \
     {                                                                                                    \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_roipool_fwd_sat<CGV>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX); \
         (void)attr;                                                                                      \
-        hipLaunchKernelGGL(k_roipool_fwd_sat<CGV>, grid, dim3(RF_THREADS), L.bytes, st, fm, geo, out, R, C, H, W, \
+        hipLaunchKernelGGL(k_roipool_fwd_sat<CGV>, grid, dim3(RF_THREADS), L.bytes, st, fm, rois, out, R, C, H, W, \
                            L.LD, L.plane, per);                                                          \
     }
     if (CG == 4) D2T_LAUNCH_SAT(4) else if (CG == 2) D2T_LAUNCH_SAT(2) else D2T_LAUNCH_SAT(1)
