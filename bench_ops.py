@@ -102,6 +102,36 @@ def main():
         emit("psroipool", f"R{R}_nT{nT}_{H}x{W}_k{k}", "bwd", timed(lambda i: _check(L.d2t_psroipool_bwd_f32(
             go[i].data_ptr(), rois.data_ptr(), gin[i].data_ptr(), R, nT, H, W, k, wb.data_ptr(), nbw, args.impl, st)), args.iters, 4), nb)
 
+    # ---- tracker glue (correlation_tracker.py:64-83): three correlations + permute + cat + ROIPool
+    #      as the reference composes them, against the fused levels call writing into the concat buffer
+    H, W, cr, R = 38, 75, 512, 8
+    Cs = (512, 1024, 2048)
+    f0 = [torch.rand(1, C, H, W, device=dev) for C in Cs]
+    f1 = [torch.rand(1, C, H, W, device=dev) for C in Cs]
+    reg0, reg1 = torch.rand(cr, H, W, device=dev), torch.rand(cr, H, W, device=dev)
+    rois_t = torch.from_numpy(random_rois(R, 2)).to(dev)
+
+    def unfused(_):
+        feats = []
+        for a, b in zip(f0, f1):
+            cf = _ext.pointwise_correlation_forward(a, b, 8, 1, args.impl)
+            feats.append(cf.squeeze(0).view(H, W, -1).permute(2, 0, 1))
+        return _ext.roipool_forward(torch.cat([reg0, reg1, *feats]), rois_t, 7, args.impl)
+
+    buf = torch.empty(1, 2 * cr + 3 * 289, H, W, device=dev)
+
+    def fused(_):
+        buf[0, :cr] = reg0
+        buf[0, cr:2 * cr] = reg1
+        _ext.pointwise_correlation_levels_forward(f0, f1, 8, 1, out=(buf, 2 * cr), impl=args.impl)
+        return _ext.roipool_forward(buf[0], rois_t, 7, args.impl)
+
+    assert torch.equal(unfused(0), fused(0))
+    nb = sum(2 * C * H * W * 4 for C in Cs) + 3 * 289 * H * W * 4
+    emit("tracker_fwd", "3corr+cat+roipool_R8_38x75", "unfused", timed(unfused, args.iters, 1), nb)
+    emit("tracker_fwd", "3corr+cat+roipool_R8_38x75", "fused", timed(fused, args.iters, 1), nb)
+    del f0, f1, buf
+
     # ---- correlation: metric shape, config 2, model-true shapes
     for B, C, H, W in ((8, 256, 38, 63), (1, 256, 38, 63), (1, 512, 38, 75), (1, 1024, 38, 75), (1, 2048, 38, 75)):
         d = 8

@@ -116,6 +116,67 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1, d
     return corr_bwd_generic<double>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
 }
 
+// ------------------------------------------------------------------ correlation, several levels / channel-major
+static int check_levels(int n, const void* const* a, const void* const* b, const void* const* c, const int* C,
+                        int B, int H, int W, int d, int s, int layout, long long bstride)
+{
+    if (n < 1 || n > tuned::MAXLV || !a || !b || !c || !C) return D2T_EINVAL;
+    if (layout != D2T_LAYOUT_REFERENCE && layout != D2T_LAYOUT_CHANNEL_MAJOR) return D2T_EINVAL;
+    const long long cells = (2LL * d + 1) * (2LL * d + 1);
+    if (layout == D2T_LAYOUT_CHANNEL_MAJOR && B > 1 && bstride < cells * H * W) return D2T_EINVAL;
+    for (int l = 0; l < n; ++l) {
+        const int rc = check_corr(a[l], b[l], c[l], B, C[l], H, W, d, s);
+        if (rc != D2T_OK) return rc;
+    }
+    if (layout == D2T_LAYOUT_CHANNEL_MAJOR && !fits_i32((B > 0 ? B - 1 : 0) * bstride + cells * H * W)) return D2T_ETOOBIG;
+    return D2T_OK;
+}
+
+int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* fm1, float* const* out, const int* C,
+                            int B, int H, int W, int d, int stride, int layout, long long bstride,
+                            void*, size_t, int impl, d2t_stream_t stream)
+{
+    int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)out, C, B, H, W, d, stride, layout, bstride);
+    if (rc != D2T_OK) return rc;
+    const int cells = (2 * d + 1) * (2 * d + 1), HW = H * W;
+    const tuned::CellLayout lay = layout == D2T_LAYOUT_CHANNEL_MAJOR ? tuned::CellLayout{1, HW, bstride}
+                                                                     : tuned::CellLayout{cells, 1, 1LL * HW * cells};
+    bool tuned_ok = impl != D2T_IMPL_GENERIC;
+    for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_fwd_supported(B, C[l], H, W, d, stride);
+    if (tuned_ok) return tuned::corr_fwd_levels_f32(n, fm0, fm1, out, C, B, H, W, lay, as_stream(stream));
+    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    for (int l = 0; l < n; ++l) {
+        rc = corr_fwd_generic<float>(fm0[l], fm1[l], out[l], B, C[l], H, W, d, stride, as_stream(stream), lay.ps, lay.cs, lay.bs);
+        if (rc != D2T_OK) return rc;
+    }
+    return D2T_OK;
+}
+
+int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const* fm0, const float* const* fm1,
+                            float* const* gfm0, float* const* gfm1, const int* C,
+                            int B, int H, int W, int d, int stride, int layout, long long bstride,
+                            void*, size_t, int impl, d2t_stream_t stream)
+{
+    int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)gout, C, B, H, W, d, stride, layout, bstride);
+    if (rc != D2T_OK) return rc;
+    if (!gfm0 || !gfm1) return D2T_EINVAL;
+    for (int l = 0; l < n; ++l)
+        if (1LL * B * C[l] * H * W > 0 && (!gfm0[l] || !gfm1[l])) return D2T_EINVAL;
+    const int cells = (2 * d + 1) * (2 * d + 1), HW = H * W;
+    const tuned::CellLayout lay = layout == D2T_LAYOUT_CHANNEL_MAJOR ? tuned::CellLayout{1, HW, bstride}
+                                                                     : tuned::CellLayout{cells, 1, 1LL * HW * cells};
+    bool tuned_ok = impl != D2T_IMPL_GENERIC;
+    for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_bwd_supported(B, C[l], H, W, d, stride);
+    if (tuned_ok) return tuned::corr_bwd_levels_f32(n, gout, fm0, fm1, gfm0, gfm1, C, B, H, W, lay, as_stream(stream));
+    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    for (int l = 0; l < n; ++l) {
+        rc = corr_bwd_generic<float>(gout[l], fm0[l], fm1[l], gfm0[l], gfm1[l], B, C[l], H, W, d, stride, as_stream(stream),
+                                     lay.ps, lay.cs, lay.bs);
+        if (rc != D2T_OK) return rc;
+    }
+    return D2T_OK;
+}
+
 // ------------------------------------------------------------------ roipool
 size_t d2t_roipool_fwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size)
 {

@@ -76,6 +76,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Where cell (ci, cj) of pixel (i, j) of batch item b lives in the correlation output / gradOut:
+//     b * bs + (i*W + j) * ps + (ci*17 + cj) * cs          (floats)
+// reference layout (B,H,W,17,17): ps = 289, cs = 1, bs = H*W*289; channel-major (289,H,W) per item --
+// what correlation_tracker.py:64-70 makes of it with view + permute, and what ROIPool consumes --
+// ps = 1, cs = H*W, bs = the caller's distance between items (a slice of a wider concat buffer).
+// (struct CellLayout: d2t_tuned.hpp)
+
+// Up to MAXLV correlation problems of one spatial shape in a single launch (the tracker's three pyramid
+// levels, correlation_tracker.py:68-70: B = 1 grids fill a fraction of the chip each).  Workgroups
+// [wg_end[l-1], wg_end[l]) belong to level l; levels are ordered heaviest (most channels) first by the
+// host so that the long workgroups start first.
+struct FwdLevels { const float* fm0[MAXLV]; const float* fm1[MAXLV]; float* out[MAXLV]; int C[MAXLV]; int wg_end[MAXLV]; int n; };
+struct BwdLevels { const float* gout[MAXLV]; const float* fm0[MAXLV]; const float* fm1[MAXLV]; float* g0[MAXLV]; float* g1[MAXLV];
+                   int C[MAXLV]; int wg_end[MAXLV]; int n; };
+
 // ------------------------------------------------------------------------------------
 // Forward, LDS-staged segment kernel (the default when the grid fills the chip).
 // A tile-per-workgroup kernel gathers every p-tile's 19 x 20 window straight from L2 in 80-byte row
@@ -136,7 +151,7 @@ __device__ __forceinline__ void dma_wait_barrier()
 // table and issued the MFMAs of empty slots as well: 8 per SIMD.)
 __global__ void __launch_bounds__(SG_THREADS)
 k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
-               int C, int H, int W, int tiles_i, int tiles_j, int nseg)
+               int C, int H, int W, int tiles_i, int tiles_j, int nseg, CellLayout lay)
 {
     __shared__ __attribute__((aligned(16))) float smem[SG_LDS];
 
@@ -155,8 +170,9 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm1 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r0 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm0 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
+    float* outb = out + (size_t)b * lay.bs;
     const __amdgpu_buffer_rsrc_t ro =
-        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * HW * CELLS, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(outb, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
 
     const int R0 = 4 * u0 - DT > 0 ? 4 * u0 - DT : 0;                // region rows [R0, R1) inside the map
     const int R1 = 4 * (u0 + nu) + DT - 1 < H ? 4 * (u0 + nu) + DT - 1 : H;
@@ -386,6 +402,18 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
     const int nj = W - j0 < TP ? W - j0 : TP;
     const int run_ = nj * CELLS, run4 = run_ >> 2;                   // floats / whole float4s per pixel row
     const int prs = (H - 4 * u0 < 4 * nu ? H - 4 * u0 : 4 * nu);     // pixel rows that exist
+    if (lay.cs != 1) {
+        // channel-major: cell c of pixel row pr is the 16-byte piece out[c][4*u0+pr][j0..j0+3]; consecutive
+        // threads take consecutive cells (consecutive LDS words, pieces H*W*4 bytes apart in memory)
+        for (int e = tid; e < prs * CELLS; e += SG_THREADS) {
+            const int pr = e / CELLS, c = e - pr * CELLS;
+            const float* src = smem + (size_t)pr * 4 * CELLS + c;
+            float* dst = outb + (size_t)c * lay.cs + ((size_t)(4 * u0 + pr) * W + j0) * lay.ps;
+            for (int r = 0; r < nj; ++r) dst[(size_t)r * lay.ps] = src[r * CELLS];
+        }
+        D2T_STAMP(5);
+        return;
+    }
     for (int e = tid; e < prs * run4; e += SG_THREADS) {
         const int pr = e / run4, q = e - pr * run4;
         const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
@@ -396,7 +424,7 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
     const int tail = run_ - 4 * run4;                                // 0..3 floats per pixel row (nj < 4)
     for (int e = tid; e < prs * tail; e += SG_THREADS) {
         const int pr = e / tail, q = 4 * run4 + (e - pr * tail);
-        out[((size_t)b * HW + (4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
+        outb[((size_t)(4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
     }
     D2T_STAMP(5);
 #ifdef D2T_LAB
@@ -440,15 +468,26 @@ struct SegX {
 
 template <int NU, int RING>
 __global__ void __launch_bounds__(3 * NU * 64)
-k_corr_fwd_segx(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
-                int C, int H, int W, int tiles_i, int tiles_j, int nseg)
+k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, CellLayout lay)
 {
     using S = SegX<NU, RING>;
     __shared__ __attribute__((aligned(16))) float smem[S::LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // level of this workgroup (wave-uniform scalar selects: the arrays live in kernel-argument SGPRs)
+    int L = 0, wg0 = 0;
+#pragma unroll
+    for (int l = 1; l < MAXLV; ++l)
+        if (l < lv.n && (int)blockIdx.x >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
+    const float* __restrict__ fm0 = lv.fm0[0];
+    const float* __restrict__ fm1 = lv.fm1[0];
+    float* __restrict__ out = lv.out[0];
+    int C = lv.C[0], nwg = lv.wg_end[0];
+#pragma unroll
+    for (int l = 1; l < MAXLV; ++l)
+        if (L == l) { fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; out = lv.out[l]; C = lv.C[l]; nwg = lv.wg_end[l] - lv.wg_end[l - 1]; }
+    const int bid = xcd_remap((int)blockIdx.x - wg0, nwg);
     const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
     const int u0 = seg * NU, nu = tiles_i - u0 < NU ? tiles_i - u0 : NU;
     const int j0 = tj * TP, HW = H * W;
@@ -457,8 +496,9 @@ k_corr_fwd_segx(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm1 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r0 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm0 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
+    float* outb = out + (size_t)b * lay.bs;
     const __amdgpu_buffer_rsrc_t ro =
-        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * HW * CELLS, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(outb, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
 
     const int R0 = 4 * u0 - DT > 0 ? 4 * u0 - DT : 0;                // region rows [R0, R1) inside the map
     const int R1 = 4 * (u0 + nu) + DT - 1 < H ? 4 * (u0 + nu) + DT - 1 : H;
@@ -605,6 +645,17 @@ k_corr_fwd_segx(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     const int nj = W - j0 < TP ? W - j0 : TP;
     const int run = nj * CELLS, run4 = run >> 2;                     // floats / whole float4s per pixel row
     const int prs = (H - 4 * u0 < 4 * nu ? H - 4 * u0 : 4 * nu);     // pixel rows that exist
+    if (lay.cs != 1) {
+        // channel-major: cell c of pixel row pr is the 16-byte piece out[c][4*u0+pr][j0..j0+3]; consecutive
+        // threads take consecutive cells (consecutive LDS words, pieces H*W*4 bytes apart in memory)
+        for (int e = tid; e < prs * CELLS; e += S::THREADS) {
+            const int pr = e / CELLS, c = e - pr * CELLS;
+            const float* src = smem + (size_t)pr * 4 * CELLS + c;
+            float* dst = outb + (size_t)c * lay.cs + ((size_t)(4 * u0 + pr) * W + j0) * lay.ps;
+            for (int r = 0; r < nj; ++r) dst[(size_t)r * lay.ps] = src[r * CELLS];
+        }
+        return;
+    }
     for (int e = tid; e < prs * run4; e += S::THREADS) {
         const int pr = e / run4, q = e - pr * run4;
         const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
@@ -615,7 +666,7 @@ k_corr_fwd_segx(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     const int tail = run - 4 * run4;                                 // 0..3 floats per pixel row (nj < 4)
     for (int e = tid; e < prs * tail; e += S::THREADS) {
         const int pr = e / tail, q = 4 * run4 + (e - pr * tail);
-        out[((size_t)b * HW + (4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
+        outb[((size_t)(4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
     }
 }
 
@@ -630,24 +681,50 @@ bool corr_fwd_supported(int B, int C, int H, int W, int d, int s)
 
 size_t corr_fwd_ws_bytes(int, int, int, int, int, int) { return 0; }
 
-int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int, int,
-                 void*, hipStream_t st)
+// nl problems of one spatial shape (B, H, W), level l with C[l] channels.  Small grids (the model's
+// B = 1 pairs) go out as ONE launch, heaviest level first; grids that fill the chip by themselves are
+// launched one after the other.
+int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1, float* const* out, const int* C,
+                        int B, int H, int W, CellLayout lay, hipStream_t st)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     const int nseg = (tiles_i + SG_NU - 1) / SG_NU;
     const long long strip_blocks = 1LL * B * tiles_j * nseg;
     if (strip_blocks >= 192) {                       // enough segments to give (nearly) every CU one
-        hipLaunchKernelGGL(k_corr_fwd_seg, dim3((int)strip_blocks), dim3(SG_THREADS), 0, st,
-                           fm0, fm1, out, C, H, W, tiles_i, tiles_j, nseg);
-    } else if (1LL * B * tiles_j * ((tiles_i + 1) / 2) >= 160) {    // medium: segments of 2 p-tiles
-        const int ns = (tiles_i + 1) / 2;
-        hipLaunchKernelGGL((k_corr_fwd_segx<2, 4>), dim3(B * tiles_j * ns), dim3(SegX<2, 4>::THREADS), 0, st,
-                           fm0, fm1, out, C, H, W, tiles_i, tiles_j, ns);
-    } else {                                         // small batches (B = 1 pairs): one p-tile per workgroup
-        hipLaunchKernelGGL((k_corr_fwd_segx<1, 4>), dim3(B * tiles_j * tiles_i), dim3(SegX<1, 4>::THREADS), 0, st,
-                           fm0, fm1, out, C, H, W, tiles_i, tiles_j, tiles_i);
+        for (int l = 0; l < nl; ++l)
+            hipLaunchKernelGGL(k_corr_fwd_seg, dim3((int)strip_blocks), dim3(SG_THREADS), 0, st,
+                               fm0[l], fm1[l], out[l], C[l], H, W, tiles_i, tiles_j, nseg, lay);
+        return launch_status();
     }
+    int order[MAXLV];
+    for (int l = 0; l < nl; ++l) order[l] = l;
+    for (int a = 0; a < nl; ++a)                     // heaviest first (nl <= 4)
+        for (int b2 = a + 1; b2 < nl; ++b2)
+            if (C[order[b2]] > C[order[a]]) { const int t = order[a]; order[a] = order[b2]; order[b2] = t; }
+    const bool two = 1LL * B * tiles_j * ((tiles_i + 1) / 2) >= 160;   // medium grids: segments of 2 p-tiles
+    const int ns = two ? (tiles_i + 1) / 2 : tiles_i;
+    const int per_level = B * tiles_j * ns;
+    FwdLevels lv;
+    lv.n = nl;
+    for (int l = 0; l < MAXLV; ++l) {
+        const int src = order[l < nl ? l : nl - 1];
+        lv.fm0[l] = fm0[src]; lv.fm1[l] = fm1[src]; lv.out[l] = out[src]; lv.C[l] = C[src];
+        lv.wg_end[l] = per_level * ((l < nl ? l : nl - 1) + 1);
+    }
+    if (two)
+        hipLaunchKernelGGL((k_corr_fwd_segx<2, 4>), dim3(per_level * nl), dim3(SegX<2, 4>::THREADS), 0, st,
+                           lv, H, W, tiles_i, tiles_j, ns, lay);
+    else                                             // small batches (B = 1 pairs): one p-tile per workgroup
+        hipLaunchKernelGGL((k_corr_fwd_segx<1, 4>), dim3(per_level * nl), dim3(SegX<1, 4>::THREADS), 0, st,
+                           lv, H, W, tiles_i, tiles_j, ns, lay);
     return launch_status();
+}
+
+int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int, int,
+                 void*, hipStream_t st)
+{
+    const CellLayout lay{CELLS, 1, 1LL * H * W * CELLS};
+    return corr_fwd_levels_f32(1, &fm0, &fm1, &out, &C, B, H, W, lay, st);
 }
 
 // ====================================================================================
@@ -692,11 +769,11 @@ constexpr int RING_SS = Q_PER_THREAD * ST_THREADS * 4;   // 8192 floats = 32 KB 
 // depend on the super-step is folded into it once per workgroup:
 //   the quad reads gradOut[off0 + ss*step + dp*s] for the s whose bit is set in `mask`, provided
 //   lo <= ss < hi (tile row exists, tile pixel and slot row inside the map); otherwise exact 0.
-// role 0: the four cells are adjacent in one gradOut row (dp = 1); role 1: they sit in four
-// adjacent centre pixels, one cell to the left each time (dp = 289 - 1).
+// role 0: the four cells are adjacent in one gradOut row (dp = cs); role 1: they sit in four
+// adjacent centre pixels, one cell to the left each time (dp = ps - cs).  (ps, cs): CellLayout.
 struct QuadDesc { int off0, lo, hi, mask; };
 
-__device__ __forceinline__ QuadDesc strip_quad_desc(int role, int e, int H, int W, int tiles_i, int j0, int col0)
+__device__ __forceinline__ QuadDesc strip_quad_desc(int role, int e, int H, int W, int tiles_i, int j0, int col0, int ps, int cs)
 {
     const int q = e / (NACT * 64), r = e - q * (NACT * 64);
     const int a = r >> 6, l = r & 63, t = l & 15, gg = l >> 4;
@@ -713,7 +790,7 @@ __device__ __forceinline__ QuadDesc strip_quad_desc(int role, int e, int H, int 
     if (ci < 0 || ci >= 2 * DT || tj >= W || q >= KB_SS) d.mask = 0;
     // centre pixel at ss = 0 (may be negative: only dereferenced when lo <= ss)
     const int pix0 = role ? xr * W + sj : (4 * (a - 2) + tpi) * W + tj;
-    d.off0 = pix0 * CELLS + ci * CW + cj;
+    d.off0 = pix0 * ps + (ci * CW + cj) * cs;
     // validity window in ss: 0 <= u < tiles_i, ti < H, rho < H
     int lo = 2 - a, hi = tiles_i + 2 - a;
     const int hi_t = (H - tpi + 3) / 4 + 2 - a;                            // 4(ss-2+a)+tpi < H
@@ -760,7 +837,7 @@ __device__ __forceinline__ bool nonfinite4(const f32x4& d)
 
 __device__ __attribute__((noinline)) void strip_repair(int role, int lane, const float* __restrict__ gb,
                                                        const float* __restrict__ Sb, float* __restrict__ gxb,
-                                                       int cw, int C, int H, int W, int j0)
+                                                       int cw, int C, int H, int W, int j0, int ps, int cs)
 {
     const int HW = H * W;
     for (int e = lane; e < 16 * H * TP; e += 64) {
@@ -771,10 +848,10 @@ __device__ __attribute__((noinline)) void strip_repair(int role, int lane, const
         if (role == 0) {                                             // centre (y,x): walk its window of FM1
             const int lo_i = y - DT > 0 ? y - DT : 0, hi_i = y + DT < H ? y + DT : H;
             const int lo_j = x - DT > 0 ? x - DT : 0, hi_j = x + DT < W ? x + DT : W;
-            const float* gc = gb + (size_t)(y * W + x) * CELLS;
+            const float* gc = gb + (size_t)(y * W + x) * ps;
             for (int di = lo_i; di < hi_i; ++di)
                 for (int dj = lo_j; dj < hi_j; ++dj)
-                    a = __builtin_fmaf(gc[(di - y + DT) * CW + (dj - x + DT)], sc[di * W + dj], a);
+                    a = __builtin_fmaf(gc[(size_t)((di - y + DT) * CW + (dj - x + DT)) * cs], sc[di * W + dj], a);
         } else {                                                     // displaced (y,x): the centres that reach it
             const int i_lo = y - DT > 0 ? y - DT : 0, i_hi = y + DT < H - 1 ? y + DT : H - 1;
             const int j_lo = x - DT > 0 ? x - DT : 0, j_hi = x + DT < W - 1 ? x + DT : W - 1;
@@ -782,7 +859,7 @@ __device__ __attribute__((noinline)) void strip_repair(int role, int lane, const
                 if (!corr_axis_hit(i, y, H, DT, 1)) continue;
                 for (int j = j_lo; j <= j_hi; ++j) {
                     if (!corr_axis_hit(j, x, W, DT, 1)) continue;
-                    a = __builtin_fmaf(gb[((size_t)(i * W + j) * CW + (y - i + DT)) * CW + (x - j + DT)], sc[i * W + j], a);
+                    a = __builtin_fmaf(gb[(size_t)(i * W + j) * ps + (size_t)((y - i + DT) * CW + (x - j + DT)) * cs], sc[i * W + j], a);
                 }
             }
         }
@@ -793,7 +870,7 @@ __device__ __attribute__((noinline)) void strip_repair(int role, int lane, const
 __global__ void __launch_bounds__(ST_THREADS)
 k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
                  float* __restrict__ g0, float* __restrict__ g1,
-                 int B, int C, int H, int W, int tiles_i, int tiles_j)
+                 int B, int C, int H, int W, int tiles_i, int tiles_j, CellLayout lay)
 {
     __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 64 KB
 
@@ -805,7 +882,7 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
     const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
     const float* S = role ? fm0 : fm1;
     float* gx = role ? g1 : g0;
-    const float* gb = gout + (size_t)b * HW * CELLS;
+    const float* gb = gout + (size_t)b * lay.bs;
 
     const int cw = blockIdx.y * ST_CH + wave * 16;                   // first channel of this wave's c-tile
     const int cl = cw + n < C ? cw + n : C - 1;                      // lane's channel (clamped; never stored)
@@ -834,10 +911,10 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
         }
     };
     // the two ring quads this thread produces every super-step (slots >= 1600 are padding: mask 0)
-    const QuadDesc qd0 = strip_quad_desc(role, tid, H, W, tiles_i, j0, col0);
-    const QuadDesc qd1 = strip_quad_desc(role, tid + ST_THREADS, H, W, tiles_i, j0, col0);
-    const int gstep = 4 * W * CELLS;                                  // gradOut offset of 4 map rows
-    const int gdp = role ? CELLS - 1 : 1;
+    const QuadDesc qd0 = strip_quad_desc(role, tid, H, W, tiles_i, j0, col0, lay.ps, lay.cs);
+    const QuadDesc qd1 = strip_quad_desc(role, tid + ST_THREADS, H, W, tiles_i, j0, col0, lay.ps, lay.cs);
+    const int gstep = 4 * W * lay.ps;                                 // gradOut offset of 4 map rows
+    const int gdp = role ? lay.ps - lay.cs : lay.cs;
 
     // prologue: ring[0] <- super-step 0, registers <- super-step 1
     reinterpret_cast<f32x4*>(ring[0])[tid] = strip_quad_load(gb, qd0, 0, gstep, gdp);
@@ -895,7 +972,7 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
     store_tile(acc[0], tiles_i - 2);                                 // their remaining super-steps lie below the map
     store_tile(acc[1], tiles_i - 1);
     if (__builtin_expect(__any(bad), 0))                             // cold: non-finite inputs only
-        strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0);
+        strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs);
 }
 
 // The same kernel with the workgroup width as a template parameter (instantiated for 4 waves = 64
@@ -903,10 +980,24 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
 // model).  Kept separate from the 16-wave kernel above, whose code generation it perturbs (+6 %).
 template <int ST_WAVES, int PROD_WAVES>                          // MFMA waves (16 channels each) + waves that only produce G
 __global__ void __launch_bounds__((ST_WAVES + PROD_WAVES) * 64)
-k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
-                 float* __restrict__ g0, float* __restrict__ g1,
-                 int B, int C, int H, int W, int tiles_i, int tiles_j)
+k_corr_bwd_strip_n(BwdLevels lv, int B, int H, int W, int tiles_i, int tiles_j, CellLayout lay)
 {
+    // level of this workgroup, then (strip, channel block) inside the level (wave-uniform)
+    int L = 0, wg0 = 0;
+#pragma unroll
+    for (int l = 1; l < MAXLV; ++l)
+        if (l < lv.n && (int)blockIdx.x >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
+    const float* __restrict__ gout = lv.gout[0];
+    const float* __restrict__ fm0 = lv.fm0[0];
+    const float* __restrict__ fm1 = lv.fm1[0];
+    float* __restrict__ g0 = lv.g0[0];
+    float* __restrict__ g1 = lv.g1[0];
+    int C = lv.C[0];
+#pragma unroll
+    for (int l = 1; l < MAXLV; ++l)
+        if (L == l) { gout = lv.gout[l]; fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; g0 = lv.g0[l]; g1 = lv.g1[l]; C = lv.C[l]; }
+    const int nstrips = 2 * B * tiles_j, lid = (int)blockIdx.x - wg0;
+    const int blk_x = lid % nstrips, blk_y = lid / nstrips;
     constexpr int ST_THREADS = (ST_WAVES + PROD_WAVES) * 64;
     constexpr int ST_CH = ST_WAVES * 16;                             // channels per workgroup pass
     constexpr int Q_PER_THREAD = 2048 / ST_THREADS;                  // ring quads per thread (2 or 8)
@@ -915,16 +1006,16 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool mfma_wave = PROD_WAVES == 0 || wave < ST_WAVES;       // wave-uniform
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // (role, b) pairs stay on one XCD
+    const int bid = xcd_remap(blk_x, nstrips);                       // (role, b) pairs stay on one XCD
     const int tj = bid % tiles_j, b = (bid / tiles_j) % B, role = bid / (tiles_j * B);
     const int j0 = tj * TP, HW = H * W;
     const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
     const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
     const float* S = role ? fm0 : fm1;
     float* gx = role ? g1 : g0;
-    const float* gb = gout + (size_t)b * HW * CELLS;
+    const float* gb = gout + (size_t)b * lay.bs;
 
-    const int cw = blockIdx.y * ST_CH + (mfma_wave ? wave : 0) * 16;                   // first channel of this wave's c-tile
+    const int cw = blk_y * ST_CH + (mfma_wave ? wave : 0) * 16;                   // first channel of this wave's c-tile
     const int cl = cw + n < C ? cw + n : C - 1;                      // lane's channel (clamped; never stored)
     const float* sp = S + ((size_t)b * C + cl) * HW + col0;
 
@@ -953,9 +1044,9 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
     // the two ring quads this thread produces every super-step (slots >= 1600 are padding: mask 0)
     QuadDesc qd[Q_PER_THREAD];
 #pragma unroll
-    for (int k = 0; k < Q_PER_THREAD; ++k) qd[k] = strip_quad_desc(role, tid + k * ST_THREADS, H, W, tiles_i, j0, col0);
-    const int gstep = 4 * W * CELLS;                                  // gradOut offset of 4 map rows
-    const int gdp = role ? CELLS - 1 : 1;
+    for (int k = 0; k < Q_PER_THREAD; ++k) qd[k] = strip_quad_desc(role, tid + k * ST_THREADS, H, W, tiles_i, j0, col0, lay.ps, lay.cs);
+    const int gstep = 4 * W * lay.ps;                                 // gradOut offset of 4 map rows
+    const int gdp = role ? lay.ps - lay.cs : lay.cs;
 
     // prologue: ring[0] <- super-step 0, registers <- super-step 1
     f32x4 gn[Q_PER_THREAD];
@@ -1004,7 +1095,7 @@ k_corr_bwd_strip_n(const float* __restrict__ gout, const float* __restrict__ fm0
         store_tile(acc[0], tiles_i - 2);                             // their remaining super-steps lie below the map
         store_tile(acc[1], tiles_i - 1);
         if (__builtin_expect(__any(bad), 0))                         // cold: non-finite inputs only
-            strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0);
+            strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs);
     }
 }
 
@@ -1012,26 +1103,52 @@ bool corr_bwd_supported(int B, int C, int H, int W, int d, int s)
 {
     if (d != DT || s != 1 || B < 1 || C < 1 || H < 1 || W < WC) return false;
     const long long blocks = 2LL * B * ((W + TP - 1) / TP);
-    return blocks <= 0x7fffffffLL && (C + 63) / 64 <= 65535;
+    return blocks * ((C + 63) / 64) <= 0x7fffffffLL;
 }
 
 size_t corr_bwd_ws_bytes(int, int, int, int, int, int) { return 0; }
 
+// nl problems of one spatial shape.  A level whose 16-wave grid fills at least 100 CUs is launched by
+// itself (k_corr_bwd_strip); the remaining levels share ONE launch of the 4-wave kernel, heaviest first.
+int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
+                        float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st)
+{
+    const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
+    int small[MAXLV], ns = 0;
+    for (int l = 0; l < nl; ++l) {
+        const long long wide = 2LL * B * tiles_j * ((C[l] + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
+        if (wide >= 100)
+            hipLaunchKernelGGL(k_corr_bwd_strip, dim3(2 * B * tiles_j, (C[l] + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
+                               gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, tiles_i, tiles_j, lay);
+        else
+            small[ns++] = l;
+    }
+    if (ns == 0) return launch_status();
+    for (int a = 0; a < ns; ++a)                     // heaviest first (ns <= 4)
+        for (int b2 = a + 1; b2 < ns; ++b2)
+            if (C[small[b2]] > C[small[a]]) { const int t = small[a]; small[a] = small[b2]; small[b2] = t; }
+    BwdLevels lv;
+    lv.n = ns;
+    int end = 0;
+    for (int l = 0; l < MAXLV; ++l) {
+        const int src = small[l < ns ? l : ns - 1];
+        lv.gout[l] = gout[src]; lv.fm0[l] = fm0[src]; lv.fm1[l] = fm1[src]; lv.g0[l] = g0[src]; lv.g1[l] = g1[src];
+        lv.C[l] = C[src];
+        if (l < ns) end += 2 * B * tiles_j * ((C[src] + 63) / 64);
+        lv.wg_end[l] = end;
+    }
+    if (end <= 256)                                                  // at most one per CU: 4 MFMA waves (64 channels)
+        hipLaunchKernelGGL((k_corr_bwd_strip_n<4, 4>), dim3(end), dim3(512), 0, st, lv, B, H, W, tiles_i, tiles_j, lay);   // + 4 waves that only produce G
+    else                                                             // small grids: 4 waves (64 channels) per workgroup
+        hipLaunchKernelGGL((k_corr_bwd_strip_n<4, 0>), dim3(end), dim3(256), 0, st, lv, B, H, W, tiles_i, tiles_j, lay);
+    return launch_status();
+}
+
 int corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
                  int B, int C, int H, int W, int, int, void*, hipStream_t st)
 {
-    const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
-    const long long wide = 2LL * B * tiles_j * ((C + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
-    if (wide >= 100)
-        hipLaunchKernelGGL(k_corr_bwd_strip, dim3(2 * B * tiles_j, (C + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
-                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
-    else if (2LL * B * tiles_j * ((C + 63) / 64) <= 256)            // at most one per CU: 4 MFMA waves (64 channels)
-        hipLaunchKernelGGL((k_corr_bwd_strip_n<4, 4>), dim3(2 * B * tiles_j, (C + 63) / 64), dim3(512), 0, st,
-                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);   // + 4 waves that only produce G
-    else                                                             // small grids: 4 waves (64 channels) per workgroup
-        hipLaunchKernelGGL((k_corr_bwd_strip_n<4, 0>), dim3(2 * B * tiles_j, (C + 63) / 64), dim3(256), 0, st,
-                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
-    return launch_status();
+    const CellLayout lay{CELLS, 1, 1LL * H * W * CELLS};
+    return corr_bwd_levels_f32(1, &gout, &fm0, &fm1, &g0, &g1, &C, B, H, W, lay, st);
 }
 
 }}  // namespace d2t::tuned

@@ -25,7 +25,7 @@ constexpr int kBlock = 256;
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_corr_fwd_generic(const T* __restrict__ fm0, const T* __restrict__ fm1, T* __restrict__ out,
-                   int B, int C, int H, int W, int d, int s)
+                   int B, int C, int H, int W, int d, int s, int ps, int cs, long long bs)
 {
     const int cw = 2 * d + 1;
     const int plane = H * W;
@@ -44,7 +44,7 @@ k_corr_fwd_generic(const T* __restrict__ fm0, const T* __restrict__ fm1, T* __re
             for (int c = 0; c < C; ++c)                       // ascending c, fused (:105-107)
                 acc = fma_t(a[(size_t)c * plane], q[(size_t)c * plane], acc);
         }
-        out[idx] = acc;
+        out[(size_t)b * bs + (size_t)(pix - b * plane) * ps + (size_t)(ci * cw + cj) * cs] = acc;   // CellLayout
     }
 }
 
@@ -60,7 +60,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_corr_bwd_generic(const T* __restrict__ gout, const T* __restrict__ fm0, const T* __restrict__ fm1,
                    T* __restrict__ g0, T* __restrict__ g1,
-                   int B, int C, int H, int W, int d, int s)
+                   int B, int C, int H, int W, int d, int s, int ps, int cs, long long bs)
 {
     const int cw = 2 * d + 1;
     const int plane = H * W;
@@ -70,17 +70,17 @@ k_corr_bwd_generic(const T* __restrict__ gout, const T* __restrict__ fm0, const 
         const int x = idx % W, y = (idx / W) % H;
         const int b = idx / (C * plane);
         const size_t chan = (size_t)(idx / plane) * plane;       // offset of plane (b,c)
-        const T* gb = gout + (size_t)b * plane * cw * cw;
+        const T* gb = gout + (size_t)b * bs;
 
         // d/dFM0: centre (y,x), walk its window.
         T a0 = T(0);
         {
             const int lo_i = y - d > 0 ? y - d : 0, hi_i = y + d < H ? y + d : H;
             const int lo_j = x - d > 0 ? x - d : 0, hi_j = x + d < W ? x + d : W;
-            const T* gc = gb + (size_t)(y * W + x) * cw * cw;
+            const T* gc = gb + (size_t)(y * W + x) * ps;
             for (int di = lo_i; di < hi_i; di += s)
                 for (int dj = lo_j; dj < hi_j; dj += s)
-                    a0 = fma_t(gc[(di - y + d) * cw + (dj - x + d)], fm1[chan + di * W + dj], a0);
+                    a0 = fma_t(gc[(size_t)((di - y + d) * cw + (dj - x + d)) * cs], fm1[chan + di * W + dj], a0);
         }
         // d/dFM1: displaced pixel (y,x), walk the centres that reach it.
         T a1 = T(0);
@@ -91,7 +91,7 @@ k_corr_bwd_generic(const T* __restrict__ gout, const T* __restrict__ fm0, const 
                 if (!corr_axis_hit(i, y, H, d, s)) continue;
                 for (int j = j_lo; j <= j_hi; ++j) {
                     if (!corr_axis_hit(j, x, W, d, s)) continue;
-                    a1 = fma_t(gb[((size_t)(i * W + j) * cw + (y - i + d)) * cw + (x - j + d)],
+                    a1 = fma_t(gb[(size_t)(i * W + j) * ps + (size_t)((y - i + d) * cw + (x - j + d)) * cs],
                                fm0[chan + i * W + j], a1);
                 }
             }
@@ -273,23 +273,26 @@ k_psroipool_bwd_generic(const T* __restrict__ gout, const int32_t* __restrict__ 
 // launchers
 // ------------------------------------------------------------------------------------
 template <typename T>
-int corr_fwd_generic(const T* fm0, const T* fm1, T* out, int B, int C, int H, int W, int d, int s, hipStream_t st)
+int corr_fwd_generic(const T* fm0, const T* fm1, T* out, int B, int C, int H, int W, int d, int s, hipStream_t st,
+                     int ps, int cs, long long bs)
 {
+    if (ps == 0) { ps = (2 * d + 1) * (2 * d + 1); cs = 1; bs = 1LL * H * W * ps; }   // the reference's layout
     const long long total = 1LL * B * H * W * (2 * d + 1) * (2 * d + 1);
     if (total == 0) return D2T_OK;
     hipLaunchKernelGGL(k_corr_fwd_generic<T>, dim3(grid_for(total, kBlock, 256 * 32)), dim3(kBlock), 0, st,
-                       fm0, fm1, out, B, C, H, W, d, s);
+                       fm0, fm1, out, B, C, H, W, d, s, ps, cs, bs);
     return launch_status();
 }
 
 template <typename T>
 int corr_bwd_generic(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1,
-                     int B, int C, int H, int W, int d, int s, hipStream_t st)
+                     int B, int C, int H, int W, int d, int s, hipStream_t st, int ps, int cs, long long bs)
 {
+    if (ps == 0) { ps = (2 * d + 1) * (2 * d + 1); cs = 1; bs = 1LL * H * W * ps; }
     const long long total = 1LL * B * C * H * W;
     if (total == 0) return D2T_OK;
     hipLaunchKernelGGL(k_corr_bwd_generic<T>, dim3(grid_for(total, kBlock, 256 * 32)), dim3(kBlock), 0, st,
-                       gout, fm0, fm1, g0, g1, B, C, H, W, d, s);
+                       gout, fm0, fm1, g0, g1, B, C, H, W, d, s, ps, cs, bs);
     return launch_status();
 }
 
@@ -374,8 +377,8 @@ int psroipool_bwd_generic(const T* gout, const T* rois, T* gin, int32_t* cells,
 }
 
 #define D2T_INSTANTIATE(T)                                                                              \
-    template int corr_fwd_generic<T>(const T*, const T*, T*, int, int, int, int, int, int, hipStream_t); \
-    template int corr_bwd_generic<T>(const T*, const T*, const T*, T*, T*, int, int, int, int, int, int, hipStream_t); \
+    template int corr_fwd_generic<T>(const T*, const T*, T*, int, int, int, int, int, int, hipStream_t, int, int, long long); \
+    template int corr_bwd_generic<T>(const T*, const T*, const T*, T*, T*, int, int, int, int, int, int, hipStream_t, int, int, long long); \
     template int roipool_fwd_generic<T>(const T*, const T*, T*, int, int, int, int, int, hipStream_t);   \
     template int roipool_bwd_generic<T>(const T*, const T*, T*, int32_t*, int, int, int, int, int, hipStream_t); \
     template int psroipool_fwd_generic<T>(const T*, const T*, T*, int, int, int, int, int, hipStream_t); \

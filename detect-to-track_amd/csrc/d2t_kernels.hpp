@@ -8,10 +8,14 @@
 namespace d2t {
 
 // ---- type-generic, reference-order kernels (d2t_generic.hip); f32 and f64 ----
+// (ps, cs, bs): where cell c of pixel p of item b lives, b*bs + p*ps + c*cs; ps = 0 selects the reference's
+// (B,H,W,2d+1,2d+1) layout
 template <typename T> int corr_fwd_generic(const T* fm0, const T* fm1, T* out,
-                                           int B, int C, int H, int W, int d, int s, hipStream_t st);
+                                           int B, int C, int H, int W, int d, int s, hipStream_t st,
+                                           int ps = 0, int cs = 0, long long bs = 0);
 template <typename T> int corr_bwd_generic(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1,
-                                           int B, int C, int H, int W, int d, int s, hipStream_t st);
+                                           int B, int C, int H, int W, int d, int s, hipStream_t st,
+                                           int ps = 0, int cs = 0, long long bs = 0);
 template <typename T> int roipool_fwd_generic(const T* fm, const T* rois, T* out,
                                               int R, int C, int H, int W, int k, hipStream_t st);
 template <typename T> int roipool_bwd_generic(const T* gout, const T* rois, T* gin, int32_t* bins,

@@ -13,6 +13,7 @@ device first, then contiguity; both RuntimeError), allocates the outputs with ``
 (the kernels write every element, including the structural zeros the reference gets from
 ``at::zeros``), and launches the HIP kernels of libd2t_ops.so on the caller's current stream.
 """
+import ctypes
 from typing import Tuple
 
 import torch
@@ -106,6 +107,78 @@ def pointwise_correlation_backward(grad_out: Tensor, FM0: Tensor, FM1: Tensor, d
             grad_out.data_ptr(), FM0.data_ptr(), FM1.data_ptr(), g0.data_ptr(), g1.data_ptr(),
             B, C, H, W, d_max, stride, _ptr(ws), n, impl, _stream(FM0))
     _native.check(rc, "pointwise_correlation_backward")
+    return g0, g1
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def pointwise_correlation_levels_forward(FM0s, FM1s, d_max: int, stride: int, out=None,
+                                         impl: int = _native.IMPL_AUTO):
+    """Correlate several feature-map pairs that share (B, H, W) in one call (one launch for small
+    grids) and return / fill CHANNEL-MAJOR outputs: level l gives ((2d+1)^2, H, W) per batch item --
+    the tensor reference correlation_tracker.py:64-70 builds with view + permute.
+
+    out: None -> a fresh (B, L*(2d+1)^2, H, W) float32 tensor is returned, level l in channels
+    [l*(2d+1)^2, (l+1)*(2d+1)^2); or a contiguous (B, Cout, H, W) tensor plus a first channel
+    ``(tensor, c0)``: level l is written at channels c0 + l*(2d+1)^2 (a torch.cat target)."""
+    L = len(FM0s)
+    if L < 1 or L != len(FM1s):
+        raise RuntimeError("need as many FM1 as FM0 feature maps (at least one)")
+    for k, (a, b) in enumerate(zip(FM0s, FM1s)):
+        _check_input(a, f"FM0[{k}]")
+        _check_input(b, f"FM1[{k}]")
+        _same(b, a, f"FM1[{k}]", f"FM0[{k}]")
+        _same(a, FM0s[0], f"FM0[{k}]", "FM0[0]")
+        if a.dtype != torch.float32:
+            raise RuntimeError("the fused correlation path is float32 only")
+        if a.dim() != 4 or b.shape != a.shape or a.shape[0] != FM0s[0].shape[0] or a.shape[2:] != FM0s[0].shape[2:]:
+            raise RuntimeError("every level must be (B, C_l, H, W) with the same B, H, W")
+    d_max, stride = int(d_max), int(stride)
+    B, _, H, W = FM0s[0].shape
+    cells = (2 * d_max + 1) ** 2
+    dev = FM0s[0].device
+    with torch.cuda.device(dev):
+        if out is None:
+            buf, c0 = torch.empty((B, L * cells, H, W), dtype=torch.float32, device=dev), 0
+        else:
+            buf, c0 = out
+            _check_input(buf, "out")
+            if buf.dtype != torch.float32 or buf.dim() != 4 or buf.shape[0] != B or tuple(buf.shape[2:]) != (H, W) \
+                    or c0 < 0 or c0 + L * cells > buf.shape[1]:
+                raise RuntimeError(f"out must be float32 (B, >= {c0 + L * cells}, H, W), got {tuple(buf.shape)}")
+        outs = [buf[:, c0 + l * cells: c0 + (l + 1) * cells] for l in range(L)]
+        Cs = (ctypes.c_int * L)(*[int(a.shape[1]) for a in FM0s])
+        rc = _native.lib.d2t_corr_fwd_levels_f32(
+            L, _ptr_array(FM0s), _ptr_array(FM1s), _ptr_array(outs), Cs, B, H, W, d_max, stride,
+            _native.LAYOUT_CHANNEL_MAJOR, buf.shape[1] * H * W, 0, 0, impl, _stream(FM0s[0]))
+    _native.check(rc, "pointwise_correlation_levels_forward")
+    return buf
+
+
+def pointwise_correlation_levels_backward(grad, c0: int, FM0s, FM1s, d_max: int, stride: int,
+                                          impl: int = _native.IMPL_AUTO):
+    """Gradients of pointwise_correlation_levels_forward: grad is the contiguous (B, Cout, H, W) gradient
+    of the channel-major buffer, level l's cells start at channel c0 + l*(2d+1)^2.  Returns two lists."""
+    _check_input(grad, "gradOut")
+    L = len(FM0s)
+    d_max, stride = int(d_max), int(stride)
+    B, _, H, W = FM0s[0].shape
+    cells = (2 * d_max + 1) ** 2
+    if grad.dtype != torch.float32 or grad.dim() != 4 or grad.shape[0] != B or tuple(grad.shape[2:]) != (H, W) \
+            or c0 + L * cells > grad.shape[1]:
+        raise RuntimeError(f"gradOut must be float32 (B, >= {c0 + L * cells}, H, W), got {tuple(grad.shape)}")
+    with torch.cuda.device(grad.device):
+        g0 = [torch.empty_like(a) for a in FM0s]
+        g1 = [torch.empty_like(b) for b in FM1s]
+        gouts = [grad[:, c0 + l * cells: c0 + (l + 1) * cells] for l in range(L)]
+        Cs = (ctypes.c_int * L)(*[int(a.shape[1]) for a in FM0s])
+        rc = _native.lib.d2t_corr_bwd_levels_f32(
+            L, _ptr_array(gouts), _ptr_array(FM0s), _ptr_array(FM1s), _ptr_array(g0), _ptr_array(g1), Cs,
+            B, H, W, d_max, stride, _native.LAYOUT_CHANNEL_MAJOR, grad.shape[1] * H * W, 0, 0, impl, _stream(grad))
+    _native.check(rc, "pointwise_correlation_levels_backward")
     return g0, g1
 
 

@@ -90,6 +90,31 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1,
                      int B, int C, int H, int W, int d, int stride,
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
 
+/* ---------------- tracker glue: several correlations, channel-major output ----------------
+ * The reference's CorrelationTracker (correlation_tracker.py:64-83) correlates three pyramid levels
+ * with three calls, turns each (1,H,W,2d+1,2d+1) result into ((2d+1)^2,H,W) with view + permute, and
+ * torch.cat's them behind the two RPN feature maps before ROIPool.  These entry points run
+ * n_levels <= 4 correlations that share (B,H,W,d,stride) -- level l has C[l] channels -- in one
+ * call (one launch where the grids are small), and can write / read the output in the layout the
+ * concatenation needs:
+ *   D2T_LAYOUT_REFERENCE      out[l] is (B,H,W,2d+1,2d+1), batch_stride ignored
+ *   D2T_LAYOUT_CHANNEL_MAJOR  cell (ci,cj) of pixel (i,j) of item b at
+ *                             out[l][b*batch_stride + (ci*(2d+1)+cj)*H*W + i*W + j]:
+ *                             out[l] may point into a wider (channels,H,W) buffer
+ * Values are bit-identical to d2t_corr_fwd_f32 / d2t_corr_bwd_f32 on the same inputs.
+ * Arrays of pointers / channel counts are HOST arrays of n_levels entries.                      */
+enum { D2T_LAYOUT_REFERENCE = 0, D2T_LAYOUT_CHANNEL_MAJOR = 1 };
+
+int d2t_corr_fwd_levels_f32(int n_levels, const float* const* fm0, const float* const* fm1, float* const* out,
+                            const int* C, int B, int H, int W, int d, int stride,
+                            int layout, long long batch_stride,
+                            void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+int d2t_corr_bwd_levels_f32(int n_levels, const float* const* gout, const float* const* fm0, const float* const* fm1,
+                            float* const* gfm0, float* const* gfm1,
+                            const int* C, int B, int H, int W, int d, int stride,
+                            int layout, long long batch_stride,
+                            void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+
 /* ---------------- ROIPool (average) ---------------- */
 size_t d2t_roipool_fwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size);
 size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size);

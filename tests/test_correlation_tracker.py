@@ -1,0 +1,134 @@
+"""GPU tests of the fused tracker glue: several correlations in one call, written
+channel-major straight into the concatenation buffer ROIPool reads.
+
+Parity = bit-equality with the composition the reference spells out (correlation_tracker.py:64-83):
+three PointwiseCorrelation calls, view + permute, torch.cat -- built here from the (already pinned)
+single-call ops of this package.  The C ABI entry points d2t_corr_{fwd,bwd}_levels_f32 are reached
+through _ext.pointwise_correlation_levels_{forward,backward}.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _unfused(fm0s, fm1s, d, s, impl=0):
+    from detect_to_track.models import _ext
+    outs = []
+    for a, b in zip(fm0s, fm1s):
+        cf = _ext.pointwise_correlation_forward(a, b, d, s, impl)            # (B,H,W,cw,cw)
+        outs.append(cf.view(cf.size(0), cf.size(1), cf.size(2), -1).permute(0, 3, 1, 2))
+    return torch.cat(outs, 1)                                                # (B, L*cells, H, W)
+
+
+CASES = [  # (B, Cs, H, W, d, s)
+    (1, (32, 48, 80), 38, 75, 8, 1),        # the tracker's shape class: one launch of 1-tile workgroups
+    (1, (512, 1024, 2048), 38, 75, 8, 1),   # the model's real channel counts (correlation_tracker.py:68-70)
+    (2, (20, 7), 19, 33, 8, 1),             # B > 1: batch stride wider than one level
+    (3, (48,), 38, 63, 8, 1),               # 2-tile segments
+    (8, (40, 24), 38, 63, 8, 1),            # full-grid kernels, one launch per level
+    (2, (6, 9, 4, 5), 11, 13, 3, 2),        # generic kernels (d != 8): four levels
+    (1, (5,), 9, 21, 8, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=str)
+def test_levels_forward_backward_equal_unfused(case):
+    from detect_to_track.models import _ext
+    B, Cs, H, W, d, s = case
+    cells = (2 * d + 1) ** 2
+    g = torch.Generator().manual_seed(sum(Cs) * 131 + H)
+    fm0s = [torch.rand(B, C, H, W, generator=g).to(DEV) for C in Cs]
+    fm1s = [torch.rand(B, C, H, W, generator=g).to(DEV) for C in Cs]
+    want = _unfused(fm0s, fm1s, d, s)
+    got = _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s)
+    assert got.shape == want.shape and torch.equal(got, want)
+    # into the middle of a wider buffer (a torch.cat target), neighbours untouched
+    pad0, pad1 = 5, 3
+    buf = torch.full((B, pad0 + len(Cs) * cells + pad1, H, W), -7.0, device=DEV)
+    _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s, out=(buf, pad0))
+    assert torch.equal(buf[:, pad0:pad0 + len(Cs) * cells], want)
+    assert bool((buf[:, :pad0] == -7).all()) and bool((buf[:, pad0 + len(Cs) * cells:] == -7).all())
+    # backward from the buffer's gradient, in place
+    gbuf = torch.rand(B, pad0 + len(Cs) * cells + pad1, H, W, generator=g).to(DEV)
+    g0, g1 = _ext.pointwise_correlation_levels_backward(gbuf, pad0, fm0s, fm1s, d, s)
+    for l, (a, b) in enumerate(zip(fm0s, fm1s)):
+        gl = gbuf[:, pad0 + l * cells: pad0 + (l + 1) * cells].permute(0, 2, 3, 1).reshape(B, H, W, 2 * d + 1, 2 * d + 1)
+        r0, r1 = _ext.pointwise_correlation_backward(gl.contiguous(), a, b, d, s)
+        assert torch.equal(g0[l], r0) and torch.equal(g1[l], r1)
+
+
+def test_levels_match_oracle(oracle):
+    """The fused entry against the CPU oracle directly (not only against our own single-call op)."""
+    from detect_to_track.models import _ext
+    rng = np.random.default_rng(5)
+    B, Cs, H, W, d = 1, (24, 40), 38, 75, 8
+    fm0 = [rng.random((B, C, H, W), dtype=np.float32) for C in Cs]
+    fm1 = [rng.random((B, C, H, W), dtype=np.float32) for C in Cs]
+    got = _ext.pointwise_correlation_levels_forward([torch.from_numpy(a).to(DEV) for a in fm0],
+                                                    [torch.from_numpy(a).to(DEV) for a in fm1], d, 1).cpu().numpy()
+    for l in range(len(Cs)):
+        want = oracle.corr_fwd(fm0[l], fm1[l], d, 1).reshape(B, H, W, 289).transpose(0, 3, 1, 2)
+        np.testing.assert_array_equal(got[:, l * 289:(l + 1) * 289], want)
+
+
+def _reference_composition(mod, pyr0, pyr1, reg0, reg1, rois):
+    """correlation_tracker.py:55-87 spelled out with this package's single-call ops."""
+    from detect_to_track.models import PointwiseCorrelation
+    pc = PointwiseCorrelation(mod.d_max, mod.stride)
+    c3_0, c4_0, c5_0 = [pyr0[k][None] for k in ("c3", "c4", "c5")]
+    c3_1, c4_1, c5_1 = [pyr1[k][None] for k in ("c3", "c4", "c5")]
+    c3_0 = torch.nn.functional.interpolate(c3_0, scale_factor=1 / 2)
+    c3_1 = torch.nn.functional.interpolate(c3_1, scale_factor=1 / 2)
+    feats = [cf.squeeze(0).view(cf.size(1), cf.size(2), -1).permute(2, 0, 1)
+             for cf in (pc(c3_0, c3_1), pc(c4_0, c4_1), pc(c5_0, c5_1))]
+    track = torch.cat([reg0, reg1, *feats])
+    pooled = mod.pool(track, rois)
+    return mod.reg_fc(pooled.view(pooled.size(0), mod.fc_channels))
+
+
+def test_module_matches_reference_composition():
+    from detect_to_track.models import CorrelationTracker
+    torch.manual_seed(3)
+    H, W, cr = 38, 75, 16
+    mod = CorrelationTracker(8, 7, cr).to(DEV)
+    assert mod.fc_channels == (3 * 289 + 2 * cr) * 49 and mod.reg_fc.in_features == mod.fc_channels
+
+    def leaf(*shape):
+        return torch.rand(*shape, device=DEV).requires_grad_(True)
+    ins_a = dict(p0={"c3": leaf(12, 2 * H, 2 * W), "c4": leaf(20, H, W), "c5": leaf(28, H, W)},
+                 p1={"c3": leaf(12, 2 * H, 2 * W), "c4": leaf(20, H, W), "c5": leaf(28, H, W)},
+                 r0=leaf(cr, H, W), r1=leaf(cr, H, W))
+    ins_b = {k: ({kk: vv.detach().clone().requires_grad_(True) for kk, vv in v.items()} if isinstance(v, dict)
+                 else v.detach().clone().requires_grad_(True)) for k, v in ins_a.items()}
+    rois = torch.tensor([[0.5, 0.5, 0.4, 0.3], [0.2, 0.7, 0.3, 0.5], [0.8, 0.3, 0.25, 0.6]], device=DEV)
+    out_a = mod(ins_a["p0"], ins_a["p1"], ins_a["r0"], ins_a["r1"], rois)
+    out_b = _reference_composition(mod, ins_b["p0"], ins_b["p1"], ins_b["r0"], ins_b["r1"], rois)
+    assert out_a.shape == (3, 4) and torch.equal(out_a, out_b)
+    w = torch.rand_like(out_a)
+    (out_a * w).sum().backward()
+    ga = [ins_a["p0"][k].grad for k in ("c3", "c4", "c5")] + [ins_a["p1"][k].grad for k in ("c3", "c4", "c5")] + \
+         [ins_a["r0"].grad, ins_a["r1"].grad, mod.reg_fc.weight.grad.clone()]
+    mod.zero_grad()
+    (out_b * w).sum().backward()
+    gb = [ins_b["p0"][k].grad for k in ("c3", "c4", "c5")] + [ins_b["p1"][k].grad for k in ("c3", "c4", "c5")] + \
+         [ins_b["r0"].grad, ins_b["r1"].grad, mod.reg_fc.weight.grad.clone()]
+    for x, y in zip(ga, gb):
+        assert x is not None and torch.equal(x, y)
+
+
+def test_levels_argument_errors():
+    from detect_to_track.models import _ext
+    a = torch.rand(1, 4, 9, 21, device=DEV)
+    with pytest.raises(RuntimeError):
+        _ext.pointwise_correlation_levels_forward([a], [a, a], 8, 1)
+    with pytest.raises(RuntimeError, match="CPU op not implemented"):
+        _ext.pointwise_correlation_levels_forward([a.cpu()], [a.cpu()], 8, 1)
+    with pytest.raises(RuntimeError):
+        _ext.pointwise_correlation_levels_forward([a], [torch.rand(1, 4, 9, 20, device=DEV)], 8, 1)
+    with pytest.raises(RuntimeError):                            # buffer too narrow
+        _ext.pointwise_correlation_levels_forward([a], [a], 8, 1, out=(torch.empty(1, 100, 9, 21, device=DEV), 0))
+    with pytest.raises(RuntimeError):                            # more than 4 levels
+        _ext.pointwise_correlation_levels_forward([a] * 5, [a] * 5, 8, 1)
