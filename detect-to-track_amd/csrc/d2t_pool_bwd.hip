@@ -26,6 +26,8 @@
 #include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
 #include <type_traits>
+#include <cstdlib>
+#include <cstring>
 
 namespace d2t { namespace tuned {
 
@@ -511,19 +513,19 @@ k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, 
     }
 }
 
-bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
+static bool psroipool_bwd_planes_supported(int R, int nT, int H, int W, int k)
 {
     return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && H <= 4 * PX_MAXROWS && W <= 64 * PX_XG && nT * KK <= 65535;
 }
 
-size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
+static size_t psroipool_bwd_planes_ws_bytes(int R, int nT, int H, int W, int k)
 {
-    if (!psroipool_bwd_supported(R, nT, H, W, k)) return 0;
+    if (!psroipool_bwd_planes_supported(R, nT, H, W, k)) return 0;
     return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float));
 }
 
-int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
-                      void* ws, hipStream_t st)
+static int psroipool_bwd_planes_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
+                                   void* ws, hipStream_t st)
 {
     int32_t* cells = static_cast<int32_t*>(ws);                      // only the register-band form reads a cell table
     float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + bins_bytes(R));
@@ -550,6 +552,53 @@ int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, i
     const int HW = H * W;
     hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
     return launch_status();
+}
+
+// Which of the two backward designs runs.  The sorted-corner-list kernels (d2t_pool_sorted.hip) do
+// work proportional to the RoI corners per plane (4R) plus a fixed cost of three launches and a
+// 49-workgroup sort; the plane kernels above walk every RoI's rows.  Measured crossover on MI355X
+// (38x75 map, R in 300..3000 x nT in 4..31, tools/ps_scan.py): the sorted design wins from 16 targets
+// up once R * nT reaches ~16000 (R=1000 nT=16: 68 vs 89 us; R=3000 nT=31: 158 vs 277 us) and loses
+// below 8 targets at every R (R=3000 nT=4: 94 vs 59 us).
+// D2T_PS_BWD=planes|sorted overrides the choice (a lab knob for that measurement, read once).
+constexpr long long PS_SORTED_MIN_WORK = 14000;
+constexpr int PS_SORTED_MIN_TARGETS = 12;
+
+static int ps_bwd_forced()
+{
+    static const int v = [] {
+        const char* e = getenv("D2T_PS_BWD");
+        if (!e) return 0;
+        return !strcmp(e, "planes") ? 1 : !strcmp(e, "sorted") ? 2 : 0;
+    }();
+    return v;
+}
+
+static bool ps_bwd_use_sorted(int R, int nT, int H, int W, int k)
+{
+    const bool s = psroipool_bwd_sorted_supported(R, nT, H, W, k), p = psroipool_bwd_planes_supported(R, nT, H, W, k);
+    if (!s || !p) return s;
+    const int f = ps_bwd_forced();
+    if (f) return f == 2;
+    return nT >= PS_SORTED_MIN_TARGETS && 1LL * R * nT >= PS_SORTED_MIN_WORK;
+}
+
+bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
+{
+    return psroipool_bwd_sorted_supported(R, nT, H, W, k) || psroipool_bwd_planes_supported(R, nT, H, W, k);
+}
+
+size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
+{
+    return ps_bwd_use_sorted(R, nT, H, W, k) ? psroipool_bwd_sorted_ws_bytes(R, nT, H, W, k)
+                                             : psroipool_bwd_planes_ws_bytes(R, nT, H, W, k);
+}
+
+int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
+                      void* ws, hipStream_t st)
+{
+    if (ps_bwd_use_sorted(R, nT, H, W, k)) return psroipool_bwd_sorted_f32(gout, rois, gin, R, nT, H, W, k, ws, st);
+    return psroipool_bwd_planes_f32(gout, rois, gin, R, nT, H, W, k, ws, st);
 }
 
 }}  // namespace d2t::tuned

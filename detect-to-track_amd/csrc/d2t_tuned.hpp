@@ -48,4 +48,10 @@ size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k);
 int    psroipool_bwd_f32(const float* gout, const float* rois, float* gin,
                          int R, int nT, int H, int W, int k, void* ws, hipStream_t st);
 
+// d2t_pool_sorted.hip
+bool   psroipool_bwd_sorted_supported(int R, int nT, int H, int W, int k);
+size_t psroipool_bwd_sorted_ws_bytes(int R, int nT, int H, int W, int k);
+int    psroipool_bwd_sorted_f32(const float* gout, const float* rois, float* gin,
+                                int R, int nT, int H, int W, int k, void* ws, hipStream_t st);
+
 }}  // namespace d2t::tuned

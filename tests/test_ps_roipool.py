@@ -90,6 +90,7 @@ def test_known_answer_fixture():
 CASES = [  # (R, nT, H, W, k)
     (3, 1, 10, 10, 6), (11, 3, 38, 63, 7), (11, 5, 9, 14, 3), (24, 4, 38, 75, 7), (300, 21, 38, 63, 7),
     (64, 31, 38, 75, 7), (5, 2, 11, 10, 7), (1, 1, 3, 3, 1), (130, 4, 20, 20, 5),
+    (1200, 13, 38, 75, 7), (1000, 16, 21, 30, 7),        # backward through the sorted corner lists (auto dispatch)
 ]
 
 
@@ -129,6 +130,25 @@ def test_matches_live_reference(case, ref_modules):
     # channel 0 collects R*nT contributions per pixel: allow fp32 reordering noise relative to that sum
     torch.testing.assert_close(gin, ref_ps.ps_roipool_backward(gout, rois, H, W), rtol=2e-5, atol=1e-5)
     assert torch.equal(gin, _ext.ps_roipool_backward(gout, rois, H, W))        # deterministic
+
+
+def test_sorted_lists_backward_adversarial_rois(oracle):
+    """The sorted-corner-list backward (d2t_pool_sorted.hip; chosen from 12 targets and R*nT >= 14000 up)
+    on the adversarial RoIs -- clamped, empty, reversed and one-pixel bins -- repeated among random ones,
+    so that equal corner addresses span many list steps."""
+    from detect_to_track.models import _ext
+    nT, H, W, k = 16, 38, 63, 7
+    adv = np.asarray(ADVERSARIAL_ROIS, np.float32)
+    rois = np.concatenate([adv] * 60 + [random_rois(500, 3)], 0)
+    rois = rois[np.random.default_rng(5).permutation(len(rois))]
+    gout = np.random.default_rng(6).standard_normal((len(rois), nT, k, k)).astype(np.float32)
+    gin = _n(_ext.ps_roipool_backward(_t(gout), _t(rois), H, W))
+    # against the oracle in f64 (the kernel adds the f32 terms gradOut/n exactly; only the f32 division
+    # and the final rounding differ), and against the f32 oracle with its own summation noise allowed for
+    want = oracle.psroipool_bwd(gout.astype(np.float64), rois.astype(np.float64), H, W)
+    np.testing.assert_allclose(gin, want, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(gin, oracle.psroipool_bwd(gout, rois, H, W), rtol=2e-5, atol=2e-4)
+    assert np.array_equal(gin, _n(_ext.ps_roipool_backward(_t(gout), _t(rois), H, W)))
 
 
 def test_channel_collisions_and_unused_channels():
