@@ -56,16 +56,12 @@ __device__ unsigned long long* lab_stamps;                          // [workgrou
             lab_stamps[blockIdx.x * 32 + (i)] = t_;                                                   \
         }                                                                                             \
     } while (0)
-// per-wave clock reads for the backward strip kernel (csrc/lab/bwd_stamp_lab.hip); D2T_ABL: ablation mask of that lab
-#ifndef D2T_ABL
-#define D2T_ABL 0
-#endif
+// per-wave clock reads for the backward strip kernel (csrc/lab/bwd_stamp_lab.hip)
 __device__ unsigned long long* lab_wave_stamps;                     // [workgroup][wave][8]
 #define D2T_WCLK(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
 #define D2T_WCLK_DECL(...) unsigned long long __VA_ARGS__
 #define D2T_LAB_ONLY(...) __VA_ARGS__
 #else
-#define D2T_ABL 0
 #define D2T_STAMP(i)
 #define D2T_STAMP_RT(i)
 #define D2T_WCLK(var)
@@ -1035,28 +1031,14 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
 #pragma unroll
         for (int q = 0; q < KB_SS; ++q) {
             const f32x4 a4 = av;
-            if (!(D2T_ABL & 4)) av = q + 1 < KB_SS ? s_load(ss, q + 1) : s_load(ss + 1, 0);
+            av = q + 1 < KB_SS ? s_load(ss, q + 1) : s_load(ss + 1, 0);
             f32x4 bv[NACT];
 #pragma unroll
             for (int a = LO; a < HI; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
-            // One k-block of a tile's 25 is structurally zero (4 % of the MFMAs): for role 0 the last one of
-            // its oldest live tile (slot row 4*ss+3 lies below every window that ends in this super-step),
-            // for role 1 the first one of its newest (slot row 4*ss lies above every window that starts
-            // here).  Those four MFMAs go behind a wave-uniform branch.
-            const int A0 = (q == KB_SS - 1 && LO == 0) ? 1 : LO;                 // without the role-0 dead block
-            const int A1 = (q == 0 && HI == NACT) ? NACT - 1 : HI;               // without the role-1 dead block
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                            // s outer: independent accumulators
 #pragma unroll
-                for (int a = A0; a < A1; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
-            }
-            if (A0 != LO && role) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[LO] = D2T_MFMA(a4[s], bv[LO][s], acc[LO]);
-            }
-            if (A1 != HI && !role) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[HI - 1] = D2T_MFMA(a4[s], bv[HI - 1][s], acc[HI - 1]);
+                for (int a = LO; a < HI; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
             }
         }
         // hand super-step ss+1's G (requested a whole super-step ago) to the other buffer, then
@@ -1065,15 +1047,12 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
         D2T_WCLK(w_a);
         g_put(ring[cur ^ 1], tid, gn0);
         g_put(ring[cur ^ 1], tid + ST_THREADS, gn1);
-        if (!(D2T_ABL & 1)) {
-            gn0 = g_load(qd0, ss + 2);                               // past the map: all zeros
-            gn1 = g_load(qd1, ss + 2);
-        }
+        gn0 = g_load(qd0, ss + 2);                                   // past the map: all zeros
+        gn1 = g_load(qd1, ss + 2);
         D2T_WCLK(w_b);
         __syncthreads();
         D2T_WCLK(w_c);
-        if (!(D2T_ABL & 2)) store_tile(acc[0], ss - 2);              // complete after its 5th super-step
-        else asm volatile("" ::"v"(acc[0]));                         // (lab: keep the MFMAs alive without the stores)
+        store_tile(acc[0], ss - 2);                                  // complete after its 5th super-step
 #pragma unroll
         for (int a = 0; a + 1 < NACT; ++a) acc[a] = acc[a + 1];
         acc[NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1104,6 +1083,224 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
 #endif
     if (__builtin_expect(__any(bad), 0))                             // cold: non-finite inputs only
         strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs);
+}
+
+// ------------------------------------------------------------------------------------
+// The column-strip kernel again, scheduled so that the matrix pipe does not drain at the super-step
+// boundary.  Per-wave clock reads (csrc/lab/bwd_stamp_lab) of k_corr_bwd_strip at the metric shape: of
+// 16 k cycles per super-step a wave spends 8.3 k in the k-blocks, 2 k writing the ring and issuing the
+// G loads, 3.5 k in the barrier and 2 k in tile store + accumulator rotation -- and because the
+// barrier aligns the 16 waves, all of them are in those phases at the same time: the pipe is busy
+// 65 % of the kernel.  What forces the drain:
+//   * the ring put + G loads sit between a wave's last MFMA and the barrier;
+//   * `acc[a] = acc[a+1]` and the store of the finished tile read accumulators the wave's LAST MFMAs
+//     write, so every wave waits for its own MFMA tail right after the barrier.
+// Here
+//   (1) the put of super-step ss+1 and the G loads of ss+2 are issued in the MIDDLE of super-step ss
+//       (the other ring buffer is free from the barrier that ended ss-1): a wave goes from its last
+//       MFMA straight into the barrier;
+//   (2) accumulators are addressed by TILE NUMBER mod 5 and never move: the super-step loop is
+//       unrolled by five, `ss mod 5` is a template parameter, and live tile a of a super-step maps to
+//       accumulator (ss - 2 + a) mod 5 at compile time;
+//   (3) one k-block of a tile's 25 is structurally zero and is not issued (4 % of the MFMAs): for
+//       role 0 the LAST one (slot row 4*ss+3 is below every window that ends in this super-step), for
+//       role 1 the FIRST one (slot row 4*ss is above every window that starts here).  That k-block is
+//       exactly the slack needed to hand an accumulator from the tile that completes to the tile that
+//       starts: role 0 stores + clears it behind the MFMAs of k-block 4, role 1 behind those of
+//       k-block 0 -- 16 MFMAs after the tile's last one, so the store never waits for the pipe.
+// The first two and last two super-steps (tiles above / below the map) are separate instantiations;
+// which accumulators the last two use depends on tiles_i mod 5, a template parameter of the kernel.
+// Arithmetic per output element is unchanged (same k order, minus terms that are exact zeros).
+// ------------------------------------------------------------------------------------
+enum { SS_GENERIC = 0, SS_FIRST = 1, SS_SECOND = 2, SS_PENULT = 3, SS_LAST = 4 };
+
+template <bool VEC, int TMOD5>
+__global__ void __launch_bounds__(ST_THREADS)
+k_corr_bwd_strip5(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
+                  float* __restrict__ g0, float* __restrict__ g1,
+                  int B, int C, int H, int W, int tiles_i, int tiles_j, CellLayout lay)
+{
+    __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 64 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    D2T_WCLK_DECL(w_t0, w_t1, w_t2, w_t3, w_b, w_c, w_d, w_q = 0, w_put = 0, w_bar = 0, w_st = 0);
+    D2T_WCLK(w_t0);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // (role, b) pairs stay on one XCD
+    const int tj = bid % tiles_j, b = (bid / tiles_j) % B, role = bid / (tiles_j * B);
+    const int j0 = tj * TP, HW = H * W;
+    const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
+    const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
+    const float* S = role ? fm0 : fm1;
+    float* gx = role ? g1 : g0;
+    const float* gb = gout + (size_t)b * lay.bs;
+
+    // Addresses are a wave-uniform base (SGPRs) + one 32-bit lane offset, so that nothing 64-bit per
+    // lane is alive across the unrolled super-steps (the first version kept per-store pointers and
+    // spilled 286 registers).
+    const int cw = blockIdx.y * ST_CH + wave * 16;                   // first channel of this wave's c-tile (uniform)
+    const int cwl = cw < C ? cw : 0;                                 // a wave past the last channel computes on channel 0.. (never stored)
+    const int nl = cwl + n < C ? n : C - 1 - cwl;                    // lane's channel inside the c-tile (clamped; never stored)
+    const float* sb = S + ((size_t)b * C + cwl) * HW + col0;         // uniform
+    unsigned soff[KB_SS];                                            // lane offset of k-block q's piece inside a super-step
+#pragma unroll
+    for (int q = 0; q < KB_SS; ++q) {
+        const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
+        soff[q] = (unsigned)(nl * HW + xr * W + 4 * cg);
+    }
+    // S fragment of k-block 5*ss + q: group 20*ss + 4q + g.  Rows past the map carry G = 0: CLAMP (only
+    // needed from row 4*(tiles_i-1) on) reads the last map row instead.
+    auto s_load = [&](int ss, int q, auto clamp_c) -> f32x4 {
+        if constexpr (decltype(clamp_c)::value) {
+            const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
+            int rho = 4 * ss + xr;
+            rho = rho < H ? rho : H - 1;
+            return *reinterpret_cast<const f32x4u*>(sb + (unsigned)(nl * HW + rho * W + 4 * cg));
+        } else {
+            return *reinterpret_cast<const f32x4u*>(sb + 4 * ss * W + soff[q]);
+        }
+    };
+
+    f32x4 acc[NACT];                                                 // acc[k]: the live tile whose number is k mod 5
+#pragma unroll
+    for (int k = 0; k < NACT; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bool bad = false;                                                // this lane stored a non-finite value
+    float* const gxb = gx + ((size_t)b * C + cw) * HW + j0;          // uniform
+    const unsigned st_off = (unsigned)(4 * g * HW + (n >> 2) * W + (n & 3));
+    auto store_tile = [&](const f32x4& d, int u) {
+        if (u < 0 || u >= tiles_i) return;                           // uniform
+        if (4 * u + (n >> 2) >= H || j0 + (n & 3) >= W) return;
+        bad = bad || nonfinite4(d);
+        float* const t = gxb + 4 * u * W;                            // uniform
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (cw + 4 * g + r < C) (t + r * HW)[st_off] = d[r];
+    };
+    const QuadDesc qd0 = VEC ? strip_vec_desc(role, tid, H, W, tiles_i, j0, col0, lay.ps)
+                             : strip_quad_desc(role, tid, H, W, tiles_i, j0, col0, lay.ps, lay.cs);
+    const QuadDesc qd1 = VEC ? strip_vec_desc(role, tid + ST_THREADS, H, W, tiles_i, j0, col0, lay.ps)
+                             : strip_quad_desc(role, tid + ST_THREADS, H, W, tiles_i, j0, col0, lay.ps, lay.cs);
+    const int gstep = 4 * W * lay.ps;                                 // gradOut offset of 4 map rows
+    const int gdp = role ? lay.ps - lay.cs : lay.cs;
+    auto g_load = [&](const QuadDesc& d, int ss) -> f32x4 {
+        if constexpr (VEC) return strip_vec_load(gb, d, ss, gstep);
+        else return strip_quad_load(gb, d, ss, gstep, gdp);
+    };
+    auto g_put = [&](float* rb, int e, const f32x4& v) {
+        if constexpr (VEC) strip_vec_put(rb, role, e, v);
+        else reinterpret_cast<f32x4*>(rb)[e] = v;
+    };
+
+    // prologue: ring[0] <- super-step 0, registers <- super-step 1
+    g_put(ring[0], tid, g_load(qd0, 0));
+    g_put(ring[0], tid + ST_THREADS, g_load(qd1, 0));
+    f32x4 gn0 = g_load(qd0, 1);
+    f32x4 gn1 = g_load(qd1, 1);
+    f32x4 av = s_load(0, 0, std::false_type{});
+    __syncthreads();
+    D2T_WCLK(w_t1);
+    D2T_LAB_ONLY(w_d = w_t1;)
+
+    using std::integral_constant;
+    // super-step ss with ss mod 5 == PH; MODE picks the live range [LO, HI) of tiles ss-2+a
+    auto super_step = [&](int ss, auto ph_c, auto mode_c, auto role_c) {
+        constexpr int PH = decltype(ph_c)::value, MODE = decltype(mode_c)::value, ROLE = decltype(role_c)::value;
+        constexpr int LO = MODE == SS_FIRST ? 2 : MODE == SS_SECOND ? 1 : 0;
+        constexpr int HI = MODE == SS_PENULT ? NACT - 1 : MODE == SS_LAST ? NACT - 2 : NACT;
+        const int cur = ss & 1;
+        const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
+#pragma unroll
+        for (int q = 0; q < KB_SS; ++q) {
+            __builtin_amdgcn_sched_barrier(0);                       // keep a k-block's fetches and MFMAs together (register pressure)
+            const f32x4 a4 = av;
+            av = q + 1 < KB_SS ? s_load(ss, q + 1, integral_constant<bool, MODE == SS_LAST>{})
+                               : s_load(ss + 1, 0, integral_constant<bool, MODE == SS_LAST>{});
+            f32x4 bv[NACT];
+#pragma unroll
+            for (int a = LO; a < HI; ++a)
+                if (!(ROLE == 0 && a == 0 && q == KB_SS - 1) && !(ROLE == 1 && a == NACT - 1 && q == 0))
+                    bv[a] = rb[(q * NACT + a) * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                            // s outer: independent accumulators
+#pragma unroll
+                for (int a = LO; a < HI; ++a) {
+                    if (ROLE == 0 && a == 0 && q == KB_SS - 1) continue;     // structurally zero k-blocks
+                    if (ROLE == 1 && a == NACT - 1 && q == 0) continue;
+                    f32x4& d = acc[(PH + 3 + a) % NACT];             // tile ss-2+a
+                    d = D2T_MFMA(a4[s], bv[a][s], d);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 1) {                                            // G of ss+1 (requested in ss-1) -> the other buffer
+                g_put(ring[cur ^ 1], tid, gn0);
+                g_put(ring[cur ^ 1], tid + ST_THREADS, gn1);
+            }
+            if (q == 2) {                                            // request G of ss+2 (past the map: zeros)
+                gn0 = g_load(qd0, ss + 2);
+                gn1 = g_load(qd1, ss + 2);
+            }
+            if (ROLE == 0 && q == KB_SS - 1) {                       // tile ss-2 got its last MFMA in k-block 3
+                f32x4& d = acc[(PH + 3) % NACT];
+                store_tile(d, ss - 2);
+                d = f32x4{0.f, 0.f, 0.f, 0.f};                       // becomes tile ss+3 in the next super-step
+            }
+            if (ROLE == 1 && q == 0) {                               // tile ss-3 completed in ss-1; tile ss+2 starts in k-block 1
+                f32x4& d = acc[(PH + 2) % NACT];
+                store_tile(d, ss - 3);
+                d = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        D2T_WCLK(w_b);
+        __syncthreads();
+        D2T_WCLK(w_c);
+        D2T_LAB_ONLY(w_q += w_b - w_d; w_bar += w_c - w_b; w_d = w_c;)
+    };
+    auto strip = [&](auto role_c) {
+        typedef integral_constant<int, SS_GENERIC> GEN;
+        super_step(0, integral_constant<int, 0>{}, integral_constant<int, SS_FIRST>{}, role_c);
+        super_step(1, integral_constant<int, 1>{}, integral_constant<int, SS_SECOND>{}, role_c);
+        int ss = 2;
+        const int end = tiles_i - 2;
+        while (ss < end) super_step(ss++, integral_constant<int, 2>{}, GEN{}, role_c);
+        super_step(tiles_i - 2, integral_constant<int, (TMOD5 + 3) % 5>{}, integral_constant<int, SS_PENULT>{}, role_c);
+        super_step(tiles_i - 1, integral_constant<int, (TMOD5 + 4) % 5>{}, integral_constant<int, SS_LAST>{}, role_c);
+    };
+    strip(integral_constant<int, 0>{});
+    D2T_WCLK(w_t2);
+    // what is still in registers: tiles tiles_i-2, tiles_i-1 (their remaining super-steps lie below the
+    // map) and, for role 1, tiles_i-3 (completed in the last super-step); tile u is in acc[u mod 5]
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int u = tiles_i - 3 + k;
+        if (k == 0 && !role) continue;
+#pragma unroll
+        for (int r = 0; r < NACT; ++r)
+            if (u % NACT == r) store_tile(acc[r], u);
+    }
+#ifdef D2T_LAB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    D2T_WCLK(w_t3);
+    if (lane == 0) {
+        unsigned long long* o = lab_wave_stamps + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * ST_WAVES + wave) * 8;
+        o[0] = w_t0; o[1] = w_t1; o[2] = w_t2; o[3] = w_t3; o[4] = w_q; o[5] = w_put; o[6] = w_bar; o[7] = w_st;
+    }
+#endif
+    if (__builtin_expect(__any(bad), 0))                             // cold: non-finite inputs only
+        strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs);
+}
+
+template <bool VEC>
+static void launch_bwd_strip5(dim3 grid, hipStream_t st, const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
+                              int B, int C, int H, int W, int tiles_i, int tiles_j, CellLayout lay)
+{
+    switch (tiles_i % 5) {
+    case 0: hipLaunchKernelGGL((k_corr_bwd_strip5<VEC, 0>), grid, dim3(ST_THREADS), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j, lay); break;
+    case 1: hipLaunchKernelGGL((k_corr_bwd_strip5<VEC, 1>), grid, dim3(ST_THREADS), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j, lay); break;
+    case 2: hipLaunchKernelGGL((k_corr_bwd_strip5<VEC, 2>), grid, dim3(ST_THREADS), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j, lay); break;
+    case 3: hipLaunchKernelGGL((k_corr_bwd_strip5<VEC, 3>), grid, dim3(ST_THREADS), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j, lay); break;
+    default: hipLaunchKernelGGL((k_corr_bwd_strip5<VEC, 4>), grid, dim3(ST_THREADS), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j, lay); break;
+    }
 }
 
 // The same kernel with the workgroup width as a template parameter (instantiated for 4 waves = 64
@@ -1248,7 +1445,10 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
     int small[MAXLV], ns = 0;
     for (int l = 0; l < nl; ++l) {
         const long long wide = 2LL * B * tiles_j * ((C[l] + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
-        if (wide >= 100 && lay.cs == 1)
+        if (wide >= 100 && lay.cs == 1 && tiles_i >= 4)
+            launch_bwd_strip5<true>(dim3(2 * B * tiles_j, (C[l] + ST_CH - 1) / ST_CH), st, gout[l], fm0[l], fm1[l], g0[l], g1[l],
+                                    B, C[l], H, W, tiles_i, tiles_j, lay);
+        else if (wide >= 100 && lay.cs == 1)
             hipLaunchKernelGGL(k_corr_bwd_strip<true>, dim3(2 * B * tiles_j, (C[l] + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
                                gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, tiles_i, tiles_j, lay);
         else if (wide >= 100)
