@@ -31,6 +31,7 @@
 namespace d2t { namespace tuned {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load, dword aligned
 
 #define D2T_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -456,9 +457,13 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
 // barrier then publishes all parts.  (__syncthreads() would wait for vmcnt(0) and serialise the
 // latency.)  Arithmetic unchanged: bit-identical to the other forward kernels.
 // ------------------------------------------------------------------------------------
-template <int NU, int RING>
+template <int NU, int RING, bool SPLIT = false>
 struct SegX {
-    static constexpr int WAVES = 3 * NU;                             // 6*NU (tile, tile-group) tasks, two per wave
+    // 6*NU (tile, tile-group) tasks, two per wave -- or, SPLIT (one tile): FOUR waves with a tile-group and
+    // a HALF tile-group (2 of its 4 N-tiles) each, so that all four SIMDs of the CU carry 6 N-tiles
+    // instead of three carrying 8 (the B = 1 kernel is bound by its longest MFMA chain)
+    static constexpr int WAVES = SPLIT ? 4 : 3 * NU;
+    static_assert(!SPLIT || NU == 1, "SPLIT is the one-tile layout");
     static constexpr int THREADS = WAVES * 64;
     static constexpr int ROWS = 4 * NU + 2 * DT - 1;                 // window rows of a segment
     static constexpr int SLOTS = (ROWS * NCG + 15) / 16 * 16;        // 16-byte slots per channel: plane stride = 0 mod 64 dwords
@@ -478,11 +483,11 @@ struct SegX {
     static_assert(LDS * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int NU, int RING>
-__global__ void __launch_bounds__(3 * NU * 64)
+template <int NU, int RING, bool SPLIT = false>
+__global__ void __launch_bounds__((SPLIT ? 4 : 3 * NU) * 64)
 k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, CellLayout lay)
 {
-    using S = SegX<NU, RING>;
+    using S = SegX<NU, RING, SPLIT>;
     __shared__ __attribute__((aligned(16))) float smem[S::LDS];
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
@@ -554,12 +559,16 @@ k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, 
         }
     };
 
-    // ---- this wave's two tasks: id = tile*6 + tile-group
+    // ---- this wave's two tasks: id = tile*6 + tile-group.  SPLIT: task 0 is a whole tile-group (0, 2, 3, 5
+    // for waves 0..3), task 1 one half of tile-group 1 (waves 0, 1) or 4 (waves 2, 3): N-tiles
+    // {0,1} for the even wave, {2,3} for the odd one.
+    const int hsel = SPLIT ? (wave & 1) : 0;                         // which half of task 1's quad (wave-uniform)
+    auto task_id = [&](int k) { return SPLIT ? (k == 0 ? (wave < 2 ? 2 * wave : 2 * wave - 1) : (wave < 2 ? 1 : 4)) : wave + S::WAVES * k; };
     int t_tile[2], t_off[2], t_ng[2];
     bool t_on[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int id = wave + S::WAVES * k, t = id / 6, T = id - t * 6;
+        const int id = task_id(k), t = id / 6, T = id - t * 6;
         const int u = u0 + t;
         const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;              // tile's window rows inside the map
         const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
@@ -572,11 +581,12 @@ k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, 
     int l_off[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int T = (wave + S::WAVES * k) % 6;
+        const int T = task_id(k) % 6;
         int gi = 16 * T + n;
         gi = gi < t_ng[k] ? gi : (t_ng[k] > 0 ? t_ng[k] - 1 : 0);
         l_off[k] = t_on[k] ? t_off[k] - 16 * T * 4 + gi * 4 + g * S::BPL : g * S::BPL;
     }
+    if (SPLIT) l_off[1] += 2 * hsel;                                 // the half quad this wave multiplies
     const int a_off0 = SG_KC * S::BPL + g * S::APL + (t_on[0] ? t_tile[0] : 0) * 16 + n;
     const int a_off1 = SG_KC * S::BPL + g * S::APL + (t_on[1] ? t_tile[1] : 0) * 16 + n;
 
@@ -594,7 +604,12 @@ k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, 
 #pragma unroll
         for (int ks = 0; ks < SG_KC / 4; ++ks) {
             f.q0[ks] = *reinterpret_cast<const f32x4*>(cur + l_off[0] + ks * 4 * S::BPL);
-            f.q1[ks] = *reinterpret_cast<const f32x4*>(cur + l_off[1] + ks * 4 * S::BPL);
+            if constexpr (SPLIT) {
+                const f32x2 h = *reinterpret_cast<const f32x2*>(cur + l_off[1] + ks * 4 * S::BPL);
+                f.q1[ks] = f32x4{h.x, h.y, 0.f, 0.f};
+            } else {
+                f.q1[ks] = *reinterpret_cast<const f32x4*>(cur + l_off[1] + ks * 4 * S::BPL);
+            }
             f.a0[ks] = cur[a_off0 + ks * 4 * S::APL];
             f.a1[ks] = cur[a_off1 + ks * 4 * S::APL];
         }
@@ -617,9 +632,9 @@ k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, 
             acc[0][1] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].y, acc[0][1]);
             acc[1][1] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].y, acc[1][1]);
             acc[0][2] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].z, acc[0][2]);
-            acc[1][2] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].z, acc[1][2]);
+            if (!SPLIT) acc[1][2] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].z, acc[1][2]);
             acc[0][3] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].w, acc[0][3]);
-            acc[1][3] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].w, acc[1][3]);
+            if (!SPLIT) acc[1][3] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].w, acc[1][3]);
         }
         dma_wait_barrier<S::INFLIGHT>();                             // chunk ch+2 has landed; chunk ch+1 is in registers
         cur_f = nxt_f;
@@ -632,7 +647,7 @@ k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, 
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int T = (wave + S::WAVES * k) % 6;
+        const int T = task_id(k) % 6;
         const int gi = 16 * T + n;
         if (t_on[k] && gi < t_ng[k]) {
             const int u = u0 + t_tile[k];
@@ -642,8 +657,8 @@ k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, 
             if (ci >= 0 && ci < 2 * DT) {
                 float* row = smem + (t_tile[k] * 16 + 4 * g) * CELLS + ci * CW;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int dj = colL + 4 * cg + s;
+                for (int s = 0; s < (SPLIT && k == 1 ? 2 : 4); ++s) {
+                    const int dj = colL + 4 * cg + s + (SPLIT && k == 1 ? 2 * hsel : 0);   // SPLIT task 1: N-tiles 2*hsel + s
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int cj = dj - (j0 + r) + DT;
@@ -727,7 +742,7 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
         hipLaunchKernelGGL((k_corr_fwd_segx<2, 4>), dim3(per_level * nl), dim3(SegX<2, 4>::THREADS), 0, st,
                            lv, H, W, tiles_i, tiles_j, ns, lay);
     else                                             // small batches (B = 1 pairs): one p-tile per workgroup
-        hipLaunchKernelGGL((k_corr_fwd_segx<1, 4>), dim3(per_level * nl), dim3(SegX<1, 4>::THREADS), 0, st,
+        hipLaunchKernelGGL((k_corr_fwd_segx<1, 4, true>), dim3(per_level * nl), dim3(SegX<1, 4, true>::THREADS), 0, st,
                            lv, H, W, tiles_i, tiles_j, ns, lay);
     return launch_status();
 }
