@@ -1,4 +1,4 @@
-// d2t_pool_sorted.hip -- ROIPool / PSROIPool backward from SORTED CORNER LISTS (gfx950, f32, k = 7).
+// d2t_pool_sorted.hip -- PSROIPool backward from SORTED CORNER LISTS (gfx950, f32, k = 7).
 //
 // gradIn of one channel is a sum of rectangles: every bin (cell) adds v = g/n to all its pixels
 // (roipool_cuda.cu:119-125, ps_roipool_cuda.cu:131-139).  A rectangle is four signed deltas in a
@@ -6,9 +6,8 @@
 // is the 2-D prefix sum of the difference map: 4 updates per bin instead of one per pixel.
 // Scattering those updates into LDS needs atomics or arbitration (round 2 measured a tag-arbitrated
 // version: 2x SLOWER than per-pixel adds, every update a chain of dependent LDS round trips).  The
-// geometry, however, does not depend on the channel (ROIPool: 1024 channels share the 300 RoIs;
-// PSROIPool: the nT targets of a bin share its cells), so the scatter is turned into a gather ONCE
-// per call:
+// geometry, however, does not depend on the target (the nT targets of a bin share its R cells), so
+// the scatter is turned into a gather ONCE per call:
 //
 //   1. k_*_corner_lists: the corners of a list's rectangles are SORTED by map address (stable LSD
 //      radix sort in LDS, ballot ranks + scanned digit counts, no atomics), packed as {sign, value

@@ -4,8 +4,7 @@
 // ~0 flops; PSROIPool at the model's shapes: 17 MB of map against 2 MB of output).  Round 1 gathered
 // every bin's pixels from L2 / L1 and scattered every gradient into its pixels; both were bound by
 // the number of memory and LDS instructions, 10-60x off the HBM roof.  This version keeps the
-// feature map (or its gradient) of a few channels resident in LDS and touches every RoI bin a
-// constant number of times:
+// feature map of a few channels resident in LDS and touches every RoI bin a constant number of times:
 //
 //  * ROIPool forward: a workgroup builds the SUMMED-AREA TABLE of 1-4 channels in LDS (f64: exact to
 //    2^-53 of the table's magnitude) and every output is four table look-ups, whatever the bin's
