@@ -19,6 +19,7 @@
 //    of RoIs, lane = RoI; results go to a (t*49+bin, RoI) buffer and are transposed to (RoI, t, bin).
 //    Bit-identical to the reference.
 //  The backward kernels live in d2t_pool_bwd.hip.
+#include <cstdlib>
 #include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
 #include "d2t_pool_common.hpp"
@@ -192,7 +193,11 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const float* __restrict__ rois, 
 
 static int sat_cg(int C, int H, int W)
 {
-    for (int cg = 4; cg >= 1; cg >>= 1)
+    // Two channels per workgroup: 45 KB of LDS, so two workgroups share a CU and one's table build
+    // overlaps the other's look-ups (config 3: 37.5 us; 4 channels = one workgroup per CU: 40.7; 1: 47.1).
+    // D2T_SAT_CG=1|2|4 overrides (lab knob for that measurement, read once).
+    static const int top = [] { const char* e = getenv("D2T_SAT_CG"); const int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();
+    for (int cg = top; cg >= 1; cg >>= 1)
         if (sat_layout(cg, H, W).bytes <= (size_t)LDS_MAX && (cg == 1 || C >= 2 * cg)) return cg;
     return sat_layout(1, H, W).bytes <= (size_t)LDS_MAX ? 1 : 0;
 }
