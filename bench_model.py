@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench_model.py -- BASELINE.json config 4: one training step of the full DetectTrack graph on ONE MI355X.
+
+What is timed: the reference's training step (trainer.py:133-256, 270-281) for a minibatch of B frame
+pairs -- backbone on the two frames of a pair, RPN, R-FCN on both frames' regions, correlation tracker,
+the five losses summed over the minibatch, ONE backward, one SGD step -- with random weights and synthetic
+frames (there is no network for datasets or checkpoints).  What is NOT the reference's: the host-side
+label encoders, anchor decoding and NMS (numpy + third-party code) are replaced by
+fixed synthetic regions and targets of the same shapes, and the losses by plain smooth-L1 / NLL terms; the
+ops, their shapes and their call pattern are the reference's.
+
+The deliverable is the step-time breakdown: which part of a step the three custom ops
+(PointwiseCorrelation, ROIPool, PSROIPool) are.  Every call into the HIP library is bracketed by HIP
+events on torch's current stream (forward and backward alike: both go through ``_ext``), so the ops'
+device time is measured inside the running step, not in isolation.
+
+Input shape: BASELINE.json says 3x600x1000, but the reference's own tracker cannot run that shape --
+c3 (75x125 at stride 8) halves to 37x62 (correlation_tracker.py:60-61) while c4/c5 are 38x63, and the
+`torch.cat` at :72 fails.  The default here is the nearest shape the reference accepts, 608x1008
+(c4 = 38x63, the BASELINE correlation shape); `--height 608 --width 1200` is the reference's
+cfg/default.yaml INPUT_SHAPE.
+
+One JSON line on stdout.  Not the headline metric (that is bench.py).
+"""
+import argparse
+import json
+import sys
+import time
+from collections import OrderedDict, defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--height", type=int, default=608)
+    p.add_argument("--width", type=int, default=1008)
+    p.add_argument("--pairs", type=int, default=2, help="frame pairs per minibatch (BASELINE config 4: 2)")
+    p.add_argument("--rois", type=int, default=300, help="regions per frame handed to R-FCN (BASELINE config 3: 300)")
+    p.add_argument("--track-rois", type=int, default=8, help="tracked objects per pair")
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--backbone", default="resnet50")
+    p.add_argument("--lr", type=float, default=1e-5)
+    return p.parse_args(argv)
+
+
+def random_rois(R, seed):
+    """(R, 4) ijhw fractions, boxes INSIDE the frame: ROIPool gives 0/0 = NaN for a bin that lies outside the map
+    (like the reference, roipool_cuda.cu:61), and the trainer's tracked boxes are ground-truth boxes."""
+    rng = np.random.default_rng(seed)
+    ctr = rng.uniform(0.15, 0.85, (R, 2))
+    size = np.minimum(rng.uniform(0.05, 0.6, (R, 2)), 1.9 * np.minimum(ctr, 1.0 - ctr))
+    return np.concatenate([ctr, size], 1).astype(np.float32)
+
+
+class OpTimer:
+    """Brackets every tensor-level entry point of the HIP library with events on the current stream."""
+    NAMES = ("pointwise_correlation_forward", "pointwise_correlation_backward",
+             "pointwise_correlation_levels_forward", "pointwise_correlation_levels_backward",
+             "roipool_forward", "roipool_backward", "ps_roipool_forward", "ps_roipool_backward")
+
+    def __init__(self, ext):
+        self.pending = []
+        self.enabled = False
+        for name in self.NAMES:
+            setattr(ext, name, self._wrap(name, getattr(ext, name)))
+
+    def _wrap(self, name, fn):
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.pending.append((name, e0, e1))
+            return out
+        return timed
+
+    def collect(self):
+        acc = defaultdict(float)
+        calls = defaultdict(int)
+        for name, e0, e1 in self.pending:
+            acc[name] += e0.elapsed_time(e1)
+            calls[name] += 1
+        self.pending = []
+        return acc, calls
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_model.py needs an MI355X: the ops have no CPU path")
+    from detect_to_track.models import DetectTrackModule, _ext
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    timer = OpTimer(_ext)
+    # cfg/default.yaml: resnet50, first trainable stage 3, 5 areas x 3 ratios = 15 anchors, 30 classes, k = 7, d_max = 8
+    model = DetectTrackModule(args.backbone, 3, 15, 30, 7, 8, 7).to(dev)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    # cfg SGD_KWARGS with the learning rate turned down: random weights against random targets diverge at 1e-2 within two
+    # steps, and non-finite feature maps would put the ops on their (slow, cold) non-finite repair paths
+    optim = torch.optim.SGD(params, lr=args.lr, weight_decay=1e-4, momentum=0.9)
+    coefs = torch.tensor([1.0, 1.0, 1.0, 1.0, 1.0e-4], device=dev)           # cfg COEFS
+
+    H, W, B, R, Rt = args.height, args.width, args.pairs, args.rois, args.track_rois
+    frames = [torch.rand(2, 3, H, W, device=dev) for _ in range(B)]
+    with torch.no_grad():
+        fh, fw = model.backbone(frames[0][:1])["c4"].shape[-2:]
+    n_anchor = fh * fw * 15
+    rois = [[torch.from_numpy(random_rois(R, 10 * i + t)).to(dev) for t in (0, 1)] for i in range(B)]
+    trois = [torch.from_numpy(random_rois(Rt, 100 + i)).to(dev) for i in range(B)]
+    o_star = [torch.randint(0, 2, (2, n_anchor), device=dev) for _ in range(B)]
+    b_star = [torch.randn(2, n_anchor, 4, device=dev) for _ in range(B)]
+    c_star = [torch.randint(0, 31, (2 * R,), device=dev) for _ in range(B)]
+    r_star = [torch.randn(2 * R, 4, device=dev) for _ in range(B)]
+    t_star = [torch.randn(Rt, 4, device=dev) for _ in range(B)]
+    sl1 = torch.nn.functional.smooth_l1_loss
+    nll = torch.nn.functional.nll_loss
+
+    sections = ("backbone", "rpn", "rcnn", "tracker", "loss")
+
+    def step(record):
+        """One minibatch: forward of every pair, one backward, one optimizer step.  `record` collects
+        (section, start event, end event) of the forward parts."""
+        def mark():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        total = torch.zeros(5, device=dev)
+        ev = []
+        for i in range(B):
+            t0 = mark()
+            fmaps = model.backbone(frames[i])                                     # trainer.py:152
+            t1 = mark()
+            o_hat, b_hat, fm_reg = model.rpn(fmaps["c4"])                         # :164
+            t2 = mark()
+            c5_0, c5_1 = fmaps["c5"]
+            c0, b0 = model.rcnn(c5_0, rois[i][0])                                 # :207-208
+            c1, b1 = model.rcnn(c5_1, rois[i][1])
+            t3 = mark()
+            pyr0 = OrderedDict((k, fmaps[k][0]) for k in ("c3", "c4", "c5"))
+            pyr1 = OrderedDict((k, fmaps[k][1]) for k in ("c3", "c4", "c5"))
+            t_hat = model.c_tracker(pyr0, pyr1, fm_reg[0], fm_reg[1], trois[i])   # :238
+            t4 = mark()
+            c_hat, r_hat = torch.cat([c0, c1]), torch.cat([b0, b1])
+            losses = torch.stack([
+                nll(torch.log(o_hat.reshape(-1, 2) + 1e-8), o_star[i].reshape(-1)),
+                sl1(b_hat, b_star[i]),
+                nll(torch.log(c_hat + 1e-8), c_star[i]),
+                sl1(r_hat, r_star[i]),
+                sl1(t_hat, t_star[i]),
+            ])
+            total = total + losses
+            t5 = mark()
+            ev.append((t0, t1, t2, t3, t4, t5))
+        optim.zero_grad(set_to_none=True)
+        b0e = mark()
+        total.backward(coefs)                                                      # :276
+        b1e = mark()
+        optim.step()
+        b2e = mark()
+        if record is not None:
+            record.append((ev, b0e, b1e, b2e))
+        return total
+
+    print(f"[bench_model] {B} pairs of 3x{H}x{W}, c4 {fh}x{fw}, {R} regions per frame, {Rt} tracked boxes; warming up "
+          f"(first MIOpen calls compile kernels)", file=sys.stderr, flush=True)
+    for w in range(args.warmup):
+        t = time.time()
+        step(None)
+        torch.cuda.synchronize()
+        print(f"[bench_model] warmup step {w}: {time.time() - t:.1f} s", file=sys.stderr, flush=True)
+
+    timer.enabled = True
+    rec = []
+    torch.cuda.synchronize()
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record()
+    for _ in range(args.steps):
+        step(rec)
+    s1.record()
+    torch.cuda.synchronize()
+    step_ms = s0.elapsed_time(s1) / args.steps
+    with torch.no_grad():                                                         # the ops' cold non-finite paths must not be what was timed
+        fm = model.backbone(frames[0])
+        amax = {k: float(v.abs().max()) for k, v in fm.items()}
+    finite = all(np.isfinite(v) for v in amax.values()) and all(bool(torch.isfinite(p).all()) for p in params)
+    print(f"[bench_model] after the run: max |activation| {amax}, parameters finite: {finite}", file=sys.stderr, flush=True)
+    sec = defaultdict(float)
+    for ev, b0e, b1e, b2e in rec:
+        for marks in ev:
+            for k, name in enumerate(sections):
+                sec[name] += marks[k].elapsed_time(marks[k + 1])
+        sec["backward"] += b0e.elapsed_time(b1e)
+        sec["optimizer"] += b1e.elapsed_time(b2e)
+    sec = {k: v / args.steps for k, v in sec.items()}
+    ops, calls = timer.collect()
+    ops = {k: v / args.steps for k, v in ops.items()}
+    calls = {k: v // args.steps for k, v in calls.items()}
+    fam = {"correlation": sum(v for k, v in ops.items() if k.startswith("pointwise")),
+           "roipool": sum(v for k, v in ops.items() if k.startswith("roipool")),
+           "ps_roipool": sum(v for k, v in ops.items() if k.startswith("ps_roipool"))}
+    ops_ms = sum(fam.values())
+    line = {
+        "bench": "DetectTrack training step (BASELINE config 4)", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+        "weights": "random", "steps": args.steps, "warmup": args.warmup,
+        "config": {"workload": f"detecttrack_{args.backbone}_B{B}pairs_3x{H}x{W}", "pairs": B, "frame": [3, H, W],
+                   "c4": [fh, fw], "regions_per_frame": R, "tracked_boxes": Rt, "anchors": n_anchor},
+        "ms_per_step": step_ms, "pairs_per_s": B / step_ms * 1e3, "finite": finite, "max_abs_activation": amax,
+        "sections_ms": sec,
+        "custom_ops_ms": ops, "custom_ops_calls_per_step": calls, "custom_ops_by_family_ms": fam,
+        "custom_ops_ms_total": ops_ms, "custom_ops_frac_of_step": ops_ms / step_ms,
+        "note": "sections are forward parts per step (all pairs); custom_ops_* are HIP-event brackets around every call "
+                "into libd2t_ops.so (forward and backward), measured inside the running step",
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
