@@ -184,14 +184,16 @@ k_ps_corner_lists(const int4* __restrict__ cellsT, unsigned short* __restrict__ 
     unsigned* heads = b;                                             // b is free now
     for (int e = tid; e < ADDR_MAX; e += CL_THREADS) heads[e] = 0xffffffffu;
     __syncthreads();
-    for (int e = tid; e < n; e += CL_THREADS) {
+    for (int e = tid; e < n; e += CL_THREADS) {                      // the entry that opens a run stores its index ...
         const int ad = a[e] & (ADDR_MAX - 1);
         const int prev = e > 0 ? (int)(a[e - 1] & (ADDR_MAX - 1)) : -1;
-        if (prev != ad) {
-            int len = 1;
-            while (e + len < n && (int)(a[e + len] & (ADDR_MAX - 1)) == ad) ++len;
-            heads[ad] = (unsigned)e | ((unsigned)len << 16);
-        }
+        if (prev != ad) heads[ad] = (unsigned)e;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += CL_THREADS) {                      // ... the one that closes it adds the length (one writer per
+        const int ad = a[e] & (ADDR_MAX - 1);                        // address; a run at a map border can be hundreds long: no serial walk)
+        const int next = e + 1 < n ? (int)(a[e + 1] & (ADDR_MAX - 1)) : -1;
+        if (next != ad) heads[ad] |= (unsigned)(e + 1 - (int)heads[ad]) << 16;
     }
     __syncthreads();
     for (int e = tid; e < ADDR_MAX; e += CL_THREADS) sg[e] = heads[e] == 0xffffffffu ? 0u : heads[e];

@@ -108,7 +108,7 @@ int main()
     hipMalloc(&fmw, (size_t)C * H * 80 * 4); hipMalloc(&sink, 64);
     hipMemset(fmw, 0, (size_t)C * H * 80 * 4);
     const float* fm = fmw;
-    for (int W : {75, 63}) {
+    for (int W : {75, 63, 64, 76}) {                       // 64, 76: every row 16-byte aligned
         printf("W = %d\n", W);
         RUN(0, 3, 19, "dma  3 waves 19 rows")
         RUN(1, 3, 19, "regs 3 waves 19 rows")

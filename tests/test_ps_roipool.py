@@ -143,10 +143,9 @@ def test_sorted_lists_backward_adversarial_rois(oracle):
     rois = rois[np.random.default_rng(5).permutation(len(rois))]
     gout = np.random.default_rng(6).standard_normal((len(rois), nT, k, k)).astype(np.float32)
     gin = _n(_ext.ps_roipool_backward(_t(gout), _t(rois), H, W))
-    # against the oracle in f64 (the kernel adds the f32 terms gradOut/n exactly; only the f32 division
-    # and the final rounding differ), and against the f32 oracle with its own summation noise allowed for
-    want = oracle.psroipool_bwd(gout.astype(np.float64), rois.astype(np.float64), H, W)
-    np.testing.assert_allclose(gin, want, rtol=1e-5, atol=2e-5)
+    # the f32 oracle sums up to ~16 * 1160 terms of magnitude ~1 per pixel of channel 0 sequentially in f32;
+    # the kernel adds the same f32 terms exactly (f64) -- the tolerance is the ORACLE's summation noise.
+    # (An f64 oracle is no yardstick here: f64 RoI arithmetic moves floor/ceil bin bounds of these RoIs.)
     np.testing.assert_allclose(gin, oracle.psroipool_bwd(gout, rois, H, W), rtol=2e-5, atol=2e-4)
     assert np.array_equal(gin, _n(_ext.ps_roipool_backward(_t(gout), _t(rois), H, W)))
 
