@@ -20,7 +20,12 @@ c3 (75x125 at stride 8) halves to 37x62 (correlation_tracker.py:60-61) while c4/
 (c4 = 38x63, the BASELINE correlation shape); `--height 608 --width 1200` is the reference's
 cfg/default.yaml INPUT_SHAPE.
 
-One JSON line on stdout.  Not the headline metric (that is bench.py).
+Config 5 (same model, B pairs PER GPU, gradients averaged over RCCL): `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 bench_model.py --gpus N` -- detect_to_track/data_parallel.py packs the 150 MB
+of gradients into 64 MB buckets and launches each all-reduce from autograd's hooks, under the rest of the backward
+pass.  That path is covered on CPU/gloo (tests/test_data_parallel_gloo.py) and has NOT run on multi-GPU hardware.
+
+One JSON line on stdout (rank 0).  Not the headline metric (that is bench.py).
 """
 import argparse
 import json
@@ -47,6 +52,9 @@ def parse_args(argv=None):
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--backbone", default="resnet50")
     p.add_argument("--lr", type=float, default=1e-5)
+    p.add_argument("--gpus", type=int, default=1, help="ranks (BASELINE config 5); launch with torch.distributed.run, one rank per GPU")
+    p.add_argument("--bucket-mb", type=float, default=64.0, help="gradient all-reduce bucket size")
+    p.add_argument("--backend", default="nccl", help="nccl = RCCL (one GPU per rank); gloo lets several ranks rehearse on ONE GPU")
     return p.parse_args(argv)
 
 
@@ -97,9 +105,23 @@ def main(argv=None):
     args = parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("bench_model.py needs an MI355X: the ops have no CPU path")
+    import os
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench_model.py --gpus {args.gpus}")
     from detect_to_track.models import DetectTrackModule, _ext
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    buckets = None
+    if world > 1:                                                                  # config 5: weak scaling, B pairs per GPU,
+        import torch.distributed as dist                                            # gradients averaged over RCCL / xGMI
+        from detect_to_track.data_parallel import GradientBuckets
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    torch.manual_seed(0)                                                           # identical initial weights on every rank
     timer = OpTimer(_ext)
     # cfg/default.yaml: resnet50, first trainable stage 3, 5 areas x 3 ratios = 15 anchors, 30 classes, k = 7, d_max = 8
     model = DetectTrackModule(args.backbone, 3, 15, 30, 7, 8, 7).to(dev)
@@ -109,6 +131,9 @@ def main(argv=None):
     # steps, and non-finite feature maps would put the ops on their (slow, cold) non-finite repair paths
     optim = torch.optim.SGD(params, lr=args.lr, weight_decay=1e-4, momentum=0.9)
     coefs = torch.tensor([1.0, 1.0, 1.0, 1.0, 1.0e-4], device=dev)           # cfg COEFS
+    if world > 1:
+        buckets = GradientBuckets(params, bucket_mb=args.bucket_mb)
+    torch.manual_seed(1 + rank)                                                    # every rank its own frames
 
     H, W, B, R, Rt = args.height, args.width, args.pairs, args.rois, args.track_rois
     frames = [torch.rand(2, 3, H, W, device=dev) for _ in range(B)]
@@ -164,6 +189,8 @@ def main(argv=None):
         optim.zero_grad(set_to_none=True)
         b0e = mark()
         total.backward(coefs)                                                      # :276
+        if buckets is not None:
+            buckets.wait()                                                         # the all-reduces ran under the backward pass
         b1e = mark()
         optim.step()
         b2e = mark()
@@ -171,13 +198,17 @@ def main(argv=None):
             record.append((ev, b0e, b1e, b2e))
         return total
 
-    print(f"[bench_model] {B} pairs of 3x{H}x{W}, c4 {fh}x{fw}, {R} regions per frame, {Rt} tracked boxes; warming up "
-          f"(first MIOpen calls compile kernels)", file=sys.stderr, flush=True)
+    if rank == 0:
+        print(f"[bench_model] {world} rank(s) x {B} pairs of 3x{H}x{W}, c4 {fh}x{fw}, {R} regions per frame, {Rt} tracked boxes; "
+              f"warming up (first MIOpen calls compile kernels)", file=sys.stderr, flush=True)
     for w in range(args.warmup):
         t = time.time()
         step(None)
         torch.cuda.synchronize()
-        print(f"[bench_model] warmup step {w}: {time.time() - t:.1f} s", file=sys.stderr, flush=True)
+        if rank == 0:
+            print(f"[bench_model] warmup step {w}: {time.time() - t:.1f} s", file=sys.stderr, flush=True)
+    if world > 1:
+        dist.barrier()
 
     timer.enabled = True
     rec = []
@@ -189,11 +220,16 @@ def main(argv=None):
     s1.record()
     torch.cuda.synchronize()
     step_ms = s0.elapsed_time(s1) / args.steps
+    if world > 1:                                                                  # the slowest rank defines the step
+        t = torch.tensor([step_ms], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        step_ms = float(t.item())
     with torch.no_grad():                                                         # the ops' cold non-finite paths must not be what was timed
         fm = model.backbone(frames[0])
         amax = {k: float(v.abs().max()) for k, v in fm.items()}
     finite = all(np.isfinite(v) for v in amax.values()) and all(bool(torch.isfinite(p).all()) for p in params)
-    print(f"[bench_model] after the run: max |activation| {amax}, parameters finite: {finite}", file=sys.stderr, flush=True)
+    if rank == 0:
+        print(f"[bench_model] after the run: max |activation| {amax}, parameters finite: {finite}", file=sys.stderr, flush=True)
     sec = defaultdict(float)
     for ev, b0e, b1e, b2e in rec:
         for marks in ev:
@@ -210,18 +246,23 @@ def main(argv=None):
            "ps_roipool": sum(v for k, v in ops.items() if k.startswith("ps_roipool"))}
     ops_ms = sum(fam.values())
     line = {
-        "bench": "DetectTrack training step (BASELINE config 4)", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+        "bench": "DetectTrack training step (BASELINE config %d)" % (4 if world == 1 else 5), "n_gpus": world, "scaling": "weak",
+        "parallelism": f"dp{world}" if world > 1 else "single", "dtype": "f32", "data": "synthetic",
         "weights": "random", "steps": args.steps, "warmup": args.warmup,
         "config": {"workload": f"detecttrack_{args.backbone}_B{B}pairs_3x{H}x{W}", "pairs": B, "frame": [3, H, W],
                    "c4": [fh, fw], "regions_per_frame": R, "tracked_boxes": Rt, "anchors": n_anchor},
-        "ms_per_step": step_ms, "pairs_per_s": B / step_ms * 1e3, "finite": finite, "max_abs_activation": amax,
+        "ms_per_step": step_ms, "pairs_per_s": world * B / step_ms * 1e3, "pairs_per_gpu": B, "finite": finite, "max_abs_activation": amax,
         "sections_ms": sec,
         "custom_ops_ms": ops, "custom_ops_calls_per_step": calls, "custom_ops_by_family_ms": fam,
         "custom_ops_ms_total": ops_ms, "custom_ops_frac_of_step": ops_ms / step_ms,
         "note": "sections are forward parts per step (all pairs); custom_ops_* are HIP-event brackets around every call "
                 "into libd2t_ops.so (forward and backward), measured inside the running step",
     }
-    print(json.dumps(line))
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
