@@ -1,6 +1,8 @@
 // d2t_pool_bwd.hip -- gfx950-tuned f32 ROIPool / PSROIPool BACKWARD kernels (k = 7), and the
 // thread-per-output PSROIPool forward that serves small problems.
 //
+//  * ROIPool backward, round 2: a GEMM with an indicator matrix on the f32 matrix pipe (k_roi_rowlists +
+//    k_roipool_bwd_gemm below; maps up to 128 columns).  The per-pixel kernel it replaces stays for wider maps:
 //  * ROIPool backward (gather form): gradOut is transposed once to (R, 49, C); a workgroup owns
 //    (64 channels, one map row), each of its waves walks a share of the RoIs -- work items come
 //    from a row-mask table, 64 RoIs per instruction, several in flight -- and adds gradOut/n into
@@ -248,22 +250,288 @@ k_roipool_bwd_batched(const float* __restrict__ gt, const int32_t* __restrict__ 
     }
 }
 
-bool roipool_bwd_supported(int R, int C, int H, int W, int k)
+// ---------------------------------------------------------------------------------------
+// ROIPool backward as a GEMM with an indicator matrix (round 2).
+//
+// For one map row y the gradient is   gradIn[c][y][x] = sum over slots s = (r, i, j) with y in bin row i
+//                                                        of  (gradOut[r][c][i][j] / n_ij)  *  [x in bin column j],
+// i.e. D[c][x] = A[c][s] * B[s][x] with A the scaled gradients (from the (R, 49, C) copy of gradOut: the
+// 16 channels of a slot are one 64-byte line) and B a 0/1 matrix that is never stored: a lane builds
+// its entries from the slot's column bounds.  The per-pixel version above does ~180 M LDS
+// read-add-writes at config 3 and is bound by them (140 us); this form does ~2.5 M
+// v_mfma_f32_16x16x4_f32 (~38 us of matrix pipe).
+//   k_roi_rowlists      one workgroup per map row: evaluates the RoIs' bins itself (roipool_cuda.cu:32-51,
+//                       the same roi_bin as every other kernel) and compacts the row's slot list --
+//                       {gradOut offset, column bounds, 1/n} per (r, i, j), ascending -- without atomics.
+//   k_roipool_bwd_gemm  one workgroup per TASK (row, NCT c-tiles of 16 channels).  The work of a row varies 40x
+//                       between the middle of the map and its edges: tasks are numbered from the middle rows
+//                       outwards and there are more workgroups than fit the chip, so the dispatcher hands the
+//                       next task to whichever CU frees a slot.  (Measured on the way: a static grid of (row, 64
+//                       channels) workgroups 148 us -- the middle rows' workgroups, co-resident with others, set
+//                       the time; a software queue on an atomic counter 110 us -- ~3 us of atomic + broadcast
+//                       latency per task.)  The NW waves of a workgroup take every NW-th k-step (= 4 slots) for
+//                       all NCT c-tiles x XT column tiles: one entry read from the LDS copy of the list, NCT
+//                       gradOut loads (RG_PF k-steps ahead), and for every column tile the k-step reaches (a mask
+//                       the list carries: ~45 % of the tiles are skipped) an indicator and NCT MFMAs; the waves'
+//                       partial sums are added through LDS in wave order.
+// Every gradIn element is written once, in a fixed order: deterministic whichever workgroup runs a task.
+// The products with B are exact (x * 1, x * 0); gradOut / n is gradOut * (1/n) as in the per-pixel kernel
+// (<= 1 ulp; the reference's atomics leave the order open).  A slot of an empty bin has scale 0 and
+// contributes an exact 0 whatever gradOut holds there.  Non-finite gradOut: 0 * Inf = NaN reaches the
+// other columns of that channel's row -- the reference would only add it to the bin's own pixels; the
+// type-generic kernel keeps that form.
+// ---------------------------------------------------------------------------------------
+struct RmSlot { int goff; int jb; float scale; int pad; };           // 16 bytes
+// every bin row of a RoI can contain a given map row (RoIs lower than 7 pixels): 49 slots per RoI and row
+inline int rm_cap(int R) { return (R * KK + 3) & ~3; }
+static size_t rm_lists_bytes(int R, int H) { return align256((size_t)H * rm_cap(R) * sizeof(RmSlot)) + align256((size_t)H * sizeof(int)); }
+
+__global__ void __launch_bounds__(256)
+k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, int* __restrict__ rownks,
+               int R, int C, int H, int W, int cap)
+{
+    __shared__ unsigned pairs[256 * KT];                             // RoI - r0 | i << 8 | bin row height << 16
+    __shared__ int colb[256][KT];                                    // j0 | j1 << 16
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, y = blockIdx.x;
+    RmSlot* out = rowslots + (size_t)y * cap;
+    int nslots = 0;                                                  // uniform
+    for (int r0 = 0; r0 < R; r0 += 256) {
+        __syncthreads();                                             // previous chunk's tables consumed
+        int mk = 0, hgt[KT];
+        if (r0 + tid < R) {
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {                           // (q, q): row bounds of bin row q, column bounds of bin column q
+                const Bounds bq = roi_bin<float>(rois + 4 * (size_t)(r0 + tid), q, q, H, W, KT);
+                mk |= (y >= bq.i0 && y < bq.i1) ? 1 << q : 0;
+                hgt[q] = bq.i1 - bq.i0;
+                colb[tid][q] = bq.j0 | (bq.j1 << 16);
+            }
+        }
+        const int cnt = __builtin_popcount(mk);
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0, npairs = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int v = wsum[w]; base += w < wave ? v : 0; npairs += v; }
+        int pos = base + inc - cnt;
+#pragma unroll
+        for (int i = 0; i < KT; ++i)
+            if (mk & (1 << i)) pairs[pos++] = (unsigned)tid | (unsigned)i << 8 | (unsigned)hgt[i] << 16;
+        __syncthreads();
+        for (int sidx = tid; sidx < npairs * KT; sidx += 256) {
+            const int p = sidx / KT, j = sidx - p * KT;
+            const unsigned pr = pairs[p];
+            const int rl = pr & 255, i = (pr >> 8) & 7, h = pr >> 16;
+            const int jb = colb[rl][j], n = h * ((jb >> 16) - (jb & 0xffff));
+            RmSlot e;
+            e.goff = ((r0 + rl) * KK + i * KT + j) * C;              // + channel, in the (R, 49, C) copy
+            e.jb = jb;
+            e.scale = n > 0 ? 1.0f / static_cast<float>(n) : 0.f;
+            e.pad = 0;
+            out[nslots + sidx] = e;
+        }
+        nslots += npairs * KT;
+    }
+    if (tid < ((4 - (nslots & 3)) & 3)) out[nslots + tid] = RmSlot{0, 0, 0.f, 0};   // zero-scale padding to a multiple of 4
+    const int nks = (nslots + 3) >> 2;
+    if (tid == 0) rownks[y] = nks;
+    __syncthreads();                                                 // the row's list is complete (and visible to this workgroup)
+    // per k-step (4 slots): which 16-column tiles does any of its slots reach?  Stored in all four `pad`
+    // fields, so that the GEMM kernel skips the other tiles' MFMAs with a scalar test.
+    for (int ks = tid; ks < nks; ks += 256) {
+        int tm = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const RmSlot e = out[4 * ks + q];
+            const int j0 = e.jb & 0xffff, j1 = e.jb >> 16;
+            if (e.scale != 0.f && j1 > j0) tm |= ((2 << ((j1 - 1) >> 4)) - 1) & ~((1 << (j0 >> 4)) - 1);   // tiles j0/16 .. (j1-1)/16
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[4 * ks + q].pad = tm;
+    }
+}
+
+constexpr int RG_CH = 128;                    // k-steps (of 4 slots) per LDS chunk of the list: 8 KB
+constexpr int RG_PF = 4;                      // k-steps of gradOut loads in flight per wave
+
+// NCT: c-tiles (16 channels) per task, NW: waves that split a task's slots.  (NCT, NW) at config 3, whole op:
+// (1,4) 158 us, (2,4) 91 us, (4,4) 97 us, (2,2) 128 us -- fewer channels per task repeat the per-k-step
+// entry / indicator work, more make the middle rows' tasks too long.
+template <int XT, int NCT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_roipool_bwd_gemm(const float* __restrict__ gt, const RmSlot* __restrict__ rowslots, const int* __restrict__ rownks,
+                   float* __restrict__ gin, int C, int H, int W, int cap, int ncb, int ntasks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    RmSlot* list = reinterpret_cast<RmSlot*>(lds_raw);               // [4 * RG_CH]
+    f32x4* red = reinterpret_cast<f32x4*>(lds_raw + 4 * RG_CH * sizeof(RmSlot));   // [wave][c-tile * XT + x-tile][lane]
+    constexpr int NACC = NCT * XT, NTHR = NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // One task per workgroup; more workgroups than fit the chip, so the hardware dispatcher hands the next
+    // task to whichever CU frees a slot -- a work queue without the ~3 us per task an atomic counter +
+    // broadcast cost when tried.  Tasks are numbered from the MIDDLE rows outwards (mid, mid+1, mid-1, ...):
+    // RoIs crowd the middle of the map, and the long tasks should start first.
+    for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
+        const int p = t / ncb, d = (p + 1) >> 1, y = (p & 1) ? (H - 1) / 2 + d : (H - 1) / 2 - d;
+        const int c0 = (t - p * ncb) * (16 * NCT);
+        const RmSlot* sl = rowslots + (size_t)y * cap;
+        const int nks = rownks[y];
+        const float* ga[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) ga[ct] = gt + (c0 + 16 * ct + n < C ? c0 + 16 * ct + n : C - 1);   // clamped: never stored
+        f32x4 acc[NCT][XT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int x = 0; x < XT; ++x) acc[ct][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int k0 = 0; k0 < nks; k0 += RG_CH) {
+            const int kc = nks - k0 < RG_CH ? nks - k0 : RG_CH;      // k-steps in this chunk
+            if (k0) __syncthreads();                                 // previous chunk consumed
+            for (int e = tid; e < 4 * kc; e += NTHR) list[e] = sl[4 * k0 + e];
+            __syncthreads();
+            // wave w takes k-steps w, w+NW, ...; lane (n, g) takes slot 4*ks + g
+            const int mine = (kc - wave + NW - 1) / NW;
+            float av[RG_PF][NCT];
+#pragma unroll
+            for (int q = 0; q < RG_PF; ++q) {
+                const int go = q < mine ? list[4 * (wave + NW * q) + g].goff : 0;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) av[q][ct] = q < mine ? ga[ct][go] : 0.f;
+            }
+            for (int m0 = 0; m0 < mine; m0 += RG_PF) {
+#pragma unroll
+                for (int q = 0; q < RG_PF; ++q) {
+                    const int m = m0 + q;                            // this wave's m-th k-step of the chunk
+                    const RmSlot e = list[4 * (wave + NW * (m < mine ? m : 0)) + g];
+                    const float sc = m < mine ? e.scale : 0.f;
+                    float a[NCT];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) a[ct] = sc != 0.f ? av[q][ct] * sc : 0.f;
+                    const int nxt = m + RG_PF;                       // refill this register slot
+                    const int go = nxt < mine ? list[4 * (wave + NW * nxt) + g].goff : 0;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) av[q][ct] = nxt < mine ? ga[ct][go] : 0.f;
+                    const int j0 = sc != 0.f ? e.jb & 0xffff : 0, j1 = sc != 0.f ? e.jb >> 16 : 0;
+                    const int tm = m < mine ? __builtin_amdgcn_readfirstlane(e.pad) : 0;   // column tiles this k-step reaches
+#pragma unroll
+                    for (int x = 0; x < XT; ++x) {                   // B: is its column inside the slot's bin?
+                        if (!(tm & (1 << x))) continue;              // none of the 4 slots reaches this tile: B = 0 (scalar test)
+                        const int col = 16 * x + n;
+                        const float ind = col >= j0 && col < j1 ? 1.f : 0.f;
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], ind, acc[ct][x], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // partial sums of the NW waves -> LDS; wave w adds the accumulators (c-tile * XT + x) = w mod NW in wave order and stores them
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int x = 0; x < XT; ++x) red[(wave * NACC + ct * XT + x) * 64 + lane] = acc[ct][x];
+        __syncthreads();
+        for (int ai = wave; ai < NACC; ai += NW) {                   // uniform
+            f32x4 v = red[(0 * NACC + ai) * 64 + lane];
+            for (int w = 1; w < NW; ++w) {
+                const f32x4 o = red[(w * NACC + ai) * 64 + lane];
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            const int ct = ai / XT, x = ai - ct * XT;
+            const int col = 16 * x + n;                              // D[m = channel 4g + r][n = column]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + 16 * ct + 4 * g + r;
+                if (c < C && col < W) gin[((size_t)c * H + y) * W + col] = v[r];
+            }
+        }
+        __syncthreads();                                             // red and list are free again
+    }
+}
+
+static bool roipool_bwd_mfma_supported(int R, int C, int H, int W, int k)
+{
+    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && W <= 128 && H <= 65535 && 1LL * R * C * KK < 0x7fffffffLL &&
+           1LL * H * ((C + 15) / 16) < 0x7fffffffLL && 1LL * H * rm_cap(R) * (long long)sizeof(RmSlot) < 0x7fffffffLL;
+}
+
+// workspace of the GEMM form: gt | row lists | k-steps per row
+static int roipool_bwd_mfma_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, void* ws, hipStream_t st)
+{
+    char* w = static_cast<char*>(ws);
+    float* gt = reinterpret_cast<float*>(w); w += align256((size_t)R * C * KK * sizeof(float));
+    const int cap = rm_cap(R);
+    RmSlot* rowslots = reinterpret_cast<RmSlot*>(w); w += align256((size_t)H * cap * sizeof(RmSlot));
+    int* rownks = reinterpret_cast<int*>(w);
+    hipLaunchKernelGGL(k_transpose_gout, dim3(R, (C + 63) / 64), dim3(256), 0, st, gout, gt, C);   // (R,C,49) -> (R,49,C)
+    hipLaunchKernelGGL(k_roi_rowlists, dim3(H), dim3(256), 0, st, rois, rowslots, rownks, R, C, H, W, cap);
+    int rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    const int xt = (W + 15) / 16;
+    // (c-tiles per task, waves per task): D2T_ROI_CFG=1..4 -> (1,4) | (2,4) | (4,4) | (2,2); a lab knob, read once
+    static const int cfg = [] { const char* e = getenv("D2T_ROI_CFG"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }();
+    const int nct = cfg == 1 ? 1 : cfg == 3 ? 4 : 2;
+    const int ncb = (C + 16 * nct - 1) / (16 * nct), ntasks = H * ncb;
+#define D2T_LAUNCH_GEMM(XTV, NCTV, NWV)                                                                        \
+    {                                                                                                          \
+        const size_t lds = 4 * RG_CH * sizeof(RmSlot) + (size_t)NWV * NCTV * XTV * 64 * sizeof(f32x4);         \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_roipool_bwd_gemm<XTV, NCTV, NWV>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        (void)attr;                                                                                            \
+        int per_cu = (int)((size_t)(160 * 1024) / (lds + 64));                                                 \
+        const int by_waves = 16 / NWV;                                                                         \
+        per_cu = per_cu > by_waves ? by_waves : per_cu;                                                        \
+        (void)per_cu;                                                                                          \
+        const int nwg = ntasks;            /* one task per workgroup: the dispatcher is the work queue */      \
+        hipLaunchKernelGGL((k_roipool_bwd_gemm<XTV, NCTV, NWV>), dim3(nwg), dim3(NWV * 64), lds, st, gt, rowslots, rownks, gin, \
+                           C, H, W, cap, ncb, ntasks);                                                         \
+    }
+#define D2T_LAUNCH_GEMM_X(NCTV, NWV) { if (xt <= 4) D2T_LAUNCH_GEMM(4, NCTV, NWV) else if (xt <= 5) D2T_LAUNCH_GEMM(5, NCTV, NWV) else D2T_LAUNCH_GEMM(8, NCTV, NWV) }
+    if (cfg == 1) D2T_LAUNCH_GEMM_X(1, 4) else if (cfg == 2) D2T_LAUNCH_GEMM_X(2, 4) else if (cfg == 3) D2T_LAUNCH_GEMM_X(4, 4) else D2T_LAUNCH_GEMM_X(2, 2)
+#undef D2T_LAUNCH_GEMM_X
+#undef D2T_LAUNCH_GEMM
+    return launch_status();
+}
+
+static bool roipool_bwd_pixel_supported(int R, int C, int H, int W, int k)
 {
     return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && (C + 63) / 64 <= 65535 &&
            (size_t)(W + 1) * RB_LD * sizeof(float) <= 64 * 1024;
 }
 
+// D2T_ROI_BWD=pixel|mfma forces one of the two designs (a lab knob for A/B measurements, read once)
+static bool roipool_bwd_use_mfma(int R, int C, int H, int W, int k)
+{
+    static const int forced = [] { const char* e = getenv("D2T_ROI_BWD"); return !e ? 0 : !strcmp(e, "pixel") ? 1 : !strcmp(e, "mfma") ? 2 : 0; }();
+    const bool m = roipool_bwd_mfma_supported(R, C, H, W, k), p = roipool_bwd_pixel_supported(R, C, H, W, k);
+    if (!m || !p) return m;
+    return forced != 1;
+}
+
+bool roipool_bwd_supported(int R, int C, int H, int W, int k)
+{
+    return roipool_bwd_mfma_supported(R, C, H, W, k) || roipool_bwd_pixel_supported(R, C, H, W, k);
+}
+
 size_t roipool_bwd_ws_bytes(int R, int C, int H, int W, int k)
 {
     if (!roipool_bwd_supported(R, C, H, W, k)) return 0;
-    return align256((size_t)R * C * KK * sizeof(float)) + geo_bytes(R) + align256((size_t)R * H) +
-           align256((size_t)R * 64 * sizeof(float));
+    const size_t geom = geo_bytes(R) + align256((size_t)R * H) + align256((size_t)R * 64 * sizeof(float));
+    return align256((size_t)R * C * KK * sizeof(float)) + (roipool_bwd_use_mfma(R, C, H, W, k) ? rm_lists_bytes(R, H) : geom);
 }
 
-int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int,
+int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int k,
                     void* ws, hipStream_t st)
 {
+    if (roipool_bwd_use_mfma(R, C, H, W, k)) return roipool_bwd_mfma_f32(gout, rois, gin, R, C, H, W, ws, st);
     float* gt = static_cast<float*>(ws);
     int32_t* geo = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + align256((size_t)R * C * KK * sizeof(float)));
     hipLaunchKernelGGL(k_transpose_gout, dim3(R, (C + 63) / 64), dim3(256), 0, st, gout, gt, C);   // (R,C,49) -> (R,49,C)

@@ -82,6 +82,9 @@ CASES = [  # (R, C, H, W, k)
     (2, 2, 10, 10, 5), (11, 3, 38, 63, 7), (11, 2, 9, 14, 3), (24, 8, 38, 63, 7), (5, 64, 38, 75, 7),
     (40, 70, 20, 33, 7), (3, 1, 5, 5, 1), (16, 130, 38, 63, 7), (7, 256, 38, 63, 7), (9, 5, 38, 63, 2),
     (70, 9, 38, 75, 7), (33, 3, 100, 140, 7), (64, 5, 7, 9, 7),
+    # backward as a GEMM (W <= 128): 8 column tiles; 300 RoIs on a 5-row map (every bin row of a RoI contains
+    # the same map rows: up to 49 slots per RoI and row); channels not a multiple of the 32 of a task
+    (37, 19, 21, 120, 7), (300, 33, 5, 40, 7), (270, 45, 38, 63, 7),
 ]
 
 

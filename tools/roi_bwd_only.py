@@ -1,0 +1,16 @@
+"""dev helper: ROIPool backward at config 3 only (for rocprofv3 --kernel-trace --stats)."""
+import sys, torch
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "detect-to-track_amd")); sys.path.insert(0, str(ROOT))
+from detect_to_track.models import _native
+from bench_ops import random_rois, timed, _ws
+L = _native.lib
+dev = "cuda:0"; st = torch.cuda.current_stream().cuda_stream
+R, C, H, W, k = 300, 1024, 38, 63, 7
+go = [torch.rand(R, C, k, k, device=dev) for _ in range(3)]
+gin = [torch.empty(C, H, W, device=dev) for _ in range(3)]
+rois = torch.from_numpy(random_rois(R, 1)).to(dev)
+nb = L.d2t_roipool_bwd_workspace_bytes(R, C, H, W, k, 4); wb = _ws(nb, dev)
+us = timed(lambda i: L.d2t_roipool_bwd_f32(go[i].data_ptr(), rois.data_ptr(), gin[i].data_ptr(), R, C, H, W, k, wb.data_ptr(), nb, 0, st), 30, 3)
+print(f"roipool bwd R={R} C={C}: {us:.1f} us")
