@@ -255,8 +255,8 @@ k_roipool_bwd_batched(const float* __restrict__ gt, const int32_t* __restrict__ 
 //
 // For one map row y the gradient is   gradIn[c][y][x] = sum over slots s = (r, i, j) with y in bin row i
 //                                                        of  (gradOut[r][c][i][j] / n_ij)  *  [x in bin column j],
-// i.e. D[c][x] = A[c][s] * B[s][x] with A the scaled gradients (from the (R, 49, C) copy of gradOut: the
-// 16 channels of a slot are one 64-byte line) and B a 0/1 matrix that is never stored: a lane builds
+// i.e. D[c][x] = A[c][s] * B[s][x] with A the scaled gradients (read from gradOut in place, no workspace
+// copy) and B a 0/1 matrix that is never stored: a lane builds
 // its entries from the slot's column bounds.  The per-pixel version above does ~180 M LDS
 // read-add-writes at config 3 and is bound by them (140 us); this form does ~2.5 M
 // v_mfma_f32_16x16x4_f32 (~38 us of matrix pipe).
@@ -331,7 +331,7 @@ k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, in
             const int rl = pr & 255, i = (pr >> 8) & 7, h = pr >> 16;
             const int jb = colb[rl][j], n = h * ((jb >> 16) - (jb & 0xffff));
             RmSlot e;
-            e.goff = ((r0 + rl) * KK + i * KT + j) * C;              // + channel, in the (R, 49, C) copy
+            e.goff = (r0 + rl) * C * KK + i * KT + j;                // + channel * 49
             e.jb = jb;
             e.scale = n > 0 ? 1.0f / static_cast<float>(n) : 0.f;
             e.pad = 0;
@@ -366,7 +366,7 @@ constexpr int RG_PF = 4;                      // k-steps of gradOut loads in fli
 // entry / indicator work, more make the middle rows' tasks too long.
 template <int XT, int NCT, int NW>
 __global__ void __launch_bounds__(NW * 64)
-k_roipool_bwd_gemm(const float* __restrict__ gt, const RmSlot* __restrict__ rowslots, const int* __restrict__ rownks,
+k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ rowslots, const int* __restrict__ rownks,
                    float* __restrict__ gin, int C, int H, int W, int cap, int ncb, int ntasks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -386,7 +386,7 @@ k_roipool_bwd_gemm(const float* __restrict__ gt, const RmSlot* __restrict__ rows
         const int nks = rownks[y];
         const float* ga[NCT];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) ga[ct] = gt + (c0 + 16 * ct + n < C ? c0 + 16 * ct + n : C - 1);   // clamped: never stored
+        for (int ct = 0; ct < NCT; ++ct) ga[ct] = gout + (size_t)(c0 + 16 * ct + n < C ? c0 + 16 * ct + n : C - 1) * KK;   // clamped: never stored
         f32x4 acc[NCT][XT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -463,15 +463,16 @@ static bool roipool_bwd_mfma_supported(int R, int C, int H, int W, int k)
            1LL * H * ((C + 15) / 16) < 0x7fffffffLL && 1LL * H * rm_cap(R) * (long long)sizeof(RmSlot) < 0x7fffffffLL;
 }
 
-// workspace of the GEMM form: gt | row lists | k-steps per row
+// workspace of the GEMM form: row lists | k-steps per row
 static int roipool_bwd_mfma_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, void* ws, hipStream_t st)
 {
     char* w = static_cast<char*>(ws);
-    float* gt = reinterpret_cast<float*>(w); w += align256((size_t)R * C * KK * sizeof(float));
     const int cap = rm_cap(R);
     RmSlot* rowslots = reinterpret_cast<RmSlot*>(w); w += align256((size_t)H * cap * sizeof(RmSlot));
     int* rownks = reinterpret_cast<int*>(w);
-    hipLaunchKernelGGL(k_transpose_gout, dim3(R, (C + 63) / 64), dim3(256), 0, st, gout, gt, C);   // (R,C,49) -> (R,49,C)
+    // A is read from gradOut IN PLACE (16 channels of a slot = 16 lines, a 28-byte run of each feeding two
+    // k-steps): 83 us at config 3.  Reading an (R, 49, C) copy instead (one line per slot) makes the GEMM kernel
+    // 18 us faster but the copy costs 26 us and 60 MB of workspace: 91 us.
     hipLaunchKernelGGL(k_roi_rowlists, dim3(H), dim3(256), 0, st, rois, rowslots, rownks, R, C, H, W, cap);
     int rc = launch_status();
     if (rc != D2T_OK) return rc;
@@ -491,7 +492,7 @@ static int roipool_bwd_mfma_f32(const float* gout, const float* rois, float* gin
         per_cu = per_cu > by_waves ? by_waves : per_cu;                                                        \
         (void)per_cu;                                                                                          \
         const int nwg = ntasks;            /* one task per workgroup: the dispatcher is the work queue */      \
-        hipLaunchKernelGGL((k_roipool_bwd_gemm<XTV, NCTV, NWV>), dim3(nwg), dim3(NWV * 64), lds, st, gt, rowslots, rownks, gin, \
+        hipLaunchKernelGGL((k_roipool_bwd_gemm<XTV, NCTV, NWV>), dim3(nwg), dim3(NWV * 64), lds, st, gout, rowslots, rownks, gin, \
                            C, H, W, cap, ncb, ntasks);                                                         \
     }
 #define D2T_LAUNCH_GEMM_X(NCTV, NWV) { if (xt <= 4) D2T_LAUNCH_GEMM(4, NCTV, NWV) else if (xt <= 5) D2T_LAUNCH_GEMM(5, NCTV, NWV) else D2T_LAUNCH_GEMM(8, NCTV, NWV) }
@@ -525,7 +526,7 @@ size_t roipool_bwd_ws_bytes(int R, int C, int H, int W, int k)
 {
     if (!roipool_bwd_supported(R, C, H, W, k)) return 0;
     const size_t geom = geo_bytes(R) + align256((size_t)R * H) + align256((size_t)R * 64 * sizeof(float));
-    return align256((size_t)R * C * KK * sizeof(float)) + (roipool_bwd_use_mfma(R, C, H, W, k) ? rm_lists_bytes(R, H) : geom);
+    return roipool_bwd_use_mfma(R, C, H, W, k) ? rm_lists_bytes(R, H) : align256((size_t)R * C * KK * sizeof(float)) + geom;
 }
 
 int roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int k,

@@ -1,4 +1,4 @@
 #!/bin/bash
 timeout -k 10 900 python -m pytest tests/test_roipool.py tests/test_tuned_vs_generic_fuzz.py tests/test_graph_capture.py tests/test_correlation_tracker.py tests/test_model_graph.py -m gpu -q -x > gpurun_out/pytest_roi.log 2>&1
 echo "pytest rc=$?"; tail -n 3 gpurun_out/pytest_roi.log
-for m in 1 2 3 4; do echo "== CFG $m"; D2T_ROI_CFG=$m timeout -k 10 200 python bench_ops.py --iters 30 2>/dev/null | grep '"roipool"' | grep bwd | cut -c1-100; done
+timeout -k 10 200 python bench_ops.py --iters 30 2>/dev/null | grep -E '"roipool"|tracker' | cut -c1-110
