@@ -407,6 +407,7 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) av[q][ct] = q < mine ? ga[ct][go] : 0.f;
             }
+#pragma unroll 1
             for (int m0 = 0; m0 < mine; m0 += RG_PF) {
 #pragma unroll
                 for (int q = 0; q < RG_PF; ++q) {
@@ -823,13 +824,241 @@ static int psroipool_bwd_planes_f32(const float* gout, const float* rois, float*
     return launch_status();
 }
 
-// Which of the two backward designs runs.  The sorted-corner-list kernels (d2t_pool_sorted.hip) do
+// ---------------------------------------------------------------------------------------
+// PSROIPool backward as a GEMM with an indicator matrix (round 2) -- the ROIPool scheme above with the
+// TARGETS as the M dimension.  The nT output planes of one bin share their R cells, so for bin (i, j) and map
+// row y
+//     plane[t][y][x] = sum over the RoIs r whose cell row i contains y of  (gradOut[r][t][i][j] / n_r)  *  [x in cell column j of r],
+// i.e. D[t][x] = A[t][r] * B[r][x]: 49 x H small GEMMs (K ~ R * 2.8 / H) on v_mfma_f32_16x16x4_f32.
+//   k_ps_transpose_t   gradOut (R, nT, 49) -> (49, R, nTp): the nT targets of a slot are one or two 64-byte lines
+//   k_ps_pairlists     workgroup (map row y, bin row i): the RoIs whose cell row i contains y, with the column bounds
+//                      of their 7 cells -- compacted by wave scans, ascending RoI
+//   k_ps_bwd_gemm      single-wave workgroups, task = (bin, y): the list chunk goes to LDS as {gradOut offset,
+//                      column bounds, 1/n, column-tile mask of the k-step}; per k-step of 4 slots NCT loads, and
+//                      for every column tile the k-step reaches an indicator and NCT MFMAs
+//   k_psroipool_bwd_gather (above)  adds, per input channel, the planes that map to it.
+// Every plane element is written once as an ascending-RoI f32 chain: deterministic.  gradOut / n is
+// gradOut * (1/n) (<= 1 ulp; the reference's atomics leave the order open).
+// ---------------------------------------------------------------------------------------
+struct PgPair { unsigned rh; int jb[KT]; };                          // r | cell rows << 16, then j0 | j1 << 16 of the 7 cells of bin row i
+constexpr int PG_CH = 256;                                           // pairs per LDS chunk
+
+__global__ void __launch_bounds__(256)
+k_ps_transpose_t(const float* __restrict__ gout, float* __restrict__ vt, int R, int nT, int nTp)
+{
+    __shared__ float t[32 * KK + 8];
+    const int r = blockIdx.x;
+    const float* src = gout + (size_t)r * nT * KK;
+    for (int e = threadIdx.x; e < nT * KK; e += 256) t[e] = src[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < KK * nTp; e += 256) {
+        const int bin = e / nTp, tt = e - bin * nTp;
+        vt[((size_t)bin * R + r) * nTp + tt] = tt < nT ? t[tt * KK + bin] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_ps_pairlists(const float* __restrict__ rois, PgPair* __restrict__ lists, int* __restrict__ counts, int R, int H, int W)
+{
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, y = blockIdx.x, i = blockIdx.y;
+    PgPair* out = lists + ((size_t)i * H + y) * R;
+    int total = 0;                                                   // uniform
+    for (int r0 = 0; r0 < R; r0 += 256) {
+        const int r = r0 + tid;
+        PgPair e{0u, {0, 0, 0, 0, 0, 0, 0}};
+        bool in = false;
+        if (r < R) {
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {                           // cell (i, q): rows depend on i only, columns on q only
+                const Bounds c = psroi_cell<float>(rois + 4 * (size_t)r, i, q, H, W, KT);
+                if (q == 0) { in = y >= c.i0 && y < c.i1; e.rh = (unsigned)r | (unsigned)(c.i1 > c.i0 ? c.i1 - c.i0 : 0) << 16; }
+                e.jb[q] = c.j0 | (c.j1 << 16);
+            }
+        }
+        int inc = in ? 1 : 0;
+        const int mine = inc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        __syncthreads();                                             // wsum of the previous chunk consumed
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0, n = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int v = wsum[w]; base += w < wave ? v : 0; n += v; }
+        if (mine) out[total + base + inc - 1] = e;
+        total += n;
+    }
+    if (tid == 0) counts[i * H + y] = total;
+}
+
+template <int XT, int NCT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+k_ps_bwd_gemm(const float* __restrict__ vt, const PgPair* __restrict__ lists, const int* __restrict__ counts,
+              float* __restrict__ part, int R, int nT, int nTp, int H, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    RmSlot* slots = reinterpret_cast<RmSlot*>(lds_raw);              // [PG_CH]
+    f32x4* red = reinterpret_cast<f32x4*>(lds_raw + PG_CH * sizeof(RmSlot));   // [wave][c-tile * XT + x-tile][lane]
+    constexpr int NACC = NCT * XT, NTHR = NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // one task per workgroup, numbered from the middle rows outwards (see k_roipool_bwd_gemm)
+    const int task = blockIdx.x, p = task / KK, bin = task - p * KK, d = (p + 1) >> 1;
+    const int y = (p & 1) ? (H - 1) / 2 + d : (H - 1) / 2 - d, i = bin / KT, j = bin - i * KT;
+    const PgPair* src = lists + ((size_t)i * H + y) * R;
+    const int cnt = counts[i * H + y];
+    const float* va = vt + (size_t)bin * R * nTp + n;                // + r * nTp + 16 * c-tile
+    f32x4 acc[NCT][XT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int x = 0; x < XT; ++x) acc[ct][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < cnt; p0 += PG_CH) {
+        const int pc = cnt - p0 < PG_CH ? cnt - p0 : PG_CH, nsl = (pc + 3) & ~3, nks = nsl >> 2;
+        if (p0) __syncthreads();                                     // previous chunk consumed
+        for (int e = tid; e < nsl; e += NTHR) {
+            RmSlot sl{0, 0, 0.f, 0};
+            if (e < pc) {
+                const unsigned rh = src[p0 + e].rh;
+                const int jb = src[p0 + e].jb[j];
+                const int nn = (int)(rh >> 16) * ((jb >> 16) - (jb & 0xffff));
+                sl.goff = (int)(rh & 0xffff) * nTp;
+                sl.jb = jb;
+                sl.scale = nn > 0 ? 1.0f / static_cast<float>(nn) : 0.f;
+            }
+            slots[e] = sl;
+        }
+        __syncthreads();
+        for (int ks = tid; ks < nks; ks += NTHR) {                   // column tiles a k-step reaches
+            int tm = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const RmSlot e = slots[4 * ks + q];
+                const int j0 = e.jb & 0xffff, j1 = e.jb >> 16;
+                if (e.scale != 0.f && j1 > j0) tm |= ((2 << ((j1 - 1) >> 4)) - 1) & ~((1 << (j0 >> 4)) - 1);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) slots[4 * ks + q].pad = tm;
+        }
+        __syncthreads();
+        const int mine = (nks - wave + NW - 1) / NW;                 // wave w takes k-steps w, w+NW, ...
+        float av[RG_PF][NCT];
+#pragma unroll
+        for (int q = 0; q < RG_PF; ++q) {
+            const int go = q < mine ? slots[4 * (wave + NW * q) + g].goff : 0;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) av[q][ct] = q < mine ? va[go + 16 * ct] : 0.f;
+        }
+#pragma unroll 1
+        for (int m0 = 0; m0 < mine; m0 += RG_PF) {
+#pragma unroll
+            for (int q = 0; q < RG_PF; ++q) {
+                const int m = m0 + q;
+                const RmSlot e = slots[4 * (wave + NW * (m < mine ? m : 0)) + g];
+                const float sc = m < mine ? e.scale : 0.f;
+                float a[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) a[ct] = sc != 0.f ? av[q][ct] * sc : 0.f;
+                const int nxt = m + RG_PF;
+                const int go = nxt < mine ? slots[4 * (wave + NW * nxt) + g].goff : 0;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) av[q][ct] = nxt < mine ? va[go + 16 * ct] : 0.f;
+                const int j0 = sc != 0.f ? e.jb & 0xffff : 0, j1 = sc != 0.f ? e.jb >> 16 : 0;
+                const int tm = m < mine ? __builtin_amdgcn_readfirstlane(e.pad) : 0;
+#pragma unroll
+                for (int x = 0; x < XT; ++x) {
+                    if (!(tm & (1 << x))) continue;
+                    const int col = 16 * x + n;
+                    const float ind = col >= j0 && col < j1 ? 1.f : 0.f;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], ind, acc[ct][x], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial sums of the NW waves -> LDS; wave w adds the accumulators (c-tile * XT + x) = w mod NW in wave order and stores them
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int x = 0; x < XT; ++x) red[(wave * NACC + ct * XT + x) * 64 + lane] = acc[ct][x];
+    __syncthreads();
+    for (int ai = wave; ai < NACC; ai += NW) {                       // uniform
+        f32x4 v = red[(0 * NACC + ai) * 64 + lane];
+        for (int w = 1; w < NW; ++w) {
+            const f32x4 o = red[(w * NACC + ai) * 64 + lane];
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+        const int ct = ai / XT, x = ai - ct * XT;
+        const int col = 16 * x + n;                                  // D[m = target 16*ct + 4g + r][n = column]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 16 * ct + 4 * g + r;
+            if (t < nT && col < W) part[(((size_t)t * KK + bin) * H + y) * W + col] = v[r];
+        }
+    }
+}
+
+static bool psroipool_bwd_gemm_supported(int R, int nT, int H, int W, int k)
+{
+    return k == KT && R >= 1 && R <= 65535 && nT >= 1 && nT <= 32 && H >= 1 && H <= 65535 && W >= 1 && W <= 128 &&
+           1LL * KK * R * 32 < 0x7fffffffLL && 1LL * nT * KK * H * W < 0x7fffffffLL && 1LL * KK * H < 0x7fffffffLL;
+}
+
+// workspace: vt (49, R, nTp) | pair lists (7, H, R) | counts (7, H) | planes (nT*49, H*W)
+static size_t psroipool_bwd_gemm_ws_bytes(int R, int nT, int H, int W, int k)
+{
+    if (!psroipool_bwd_gemm_supported(R, nT, H, W, k)) return 0;
+    const int nTp = 32;
+    return align256((size_t)KK * R * nTp * 4) + align256((size_t)KT * H * R * sizeof(PgPair)) + align256((size_t)KT * H * 4) +
+           align256((size_t)nT * KK * H * W * 4);
+}
+
+static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, void* ws, hipStream_t st)
+{
+    // always two c-tiles (targets padded to 32 with zeros): the one-c-tile instantiation compiles to a mess of
+    // accumulator copies (356 VGPRs at 8 column tiles) and ran slower with 4 targets than this one with 31
+    const int nTp = 32;
+    char* w = static_cast<char*>(ws);
+    float* vt = reinterpret_cast<float*>(w); w += align256((size_t)KK * R * nTp * 4);
+    PgPair* lists = reinterpret_cast<PgPair*>(w); w += align256((size_t)KT * H * R * sizeof(PgPair));
+    int* counts = reinterpret_cast<int*>(w); w += align256((size_t)KT * H * 4);
+    float* part = reinterpret_cast<float*>(w);
+    hipLaunchKernelGGL(k_ps_transpose_t, dim3(R), dim3(256), 0, st, gout, vt, R, nT, nTp);
+    hipLaunchKernelGGL(k_ps_pairlists, dim3(H, KT), dim3(256), 0, st, rois, lists, counts, R, H, W);
+    int rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    const int xt = (W + 15) / 16, ntasks = KK * H;
+#define D2T_LAUNCH_PG(XTV, NCTV, NWV)                                                                          \
+    {                                                                                                          \
+        const size_t lds = PG_CH * sizeof(RmSlot) + (size_t)NWV * NCTV * XTV * 64 * sizeof(f32x4);             \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ps_bwd_gemm<XTV, NCTV, NWV>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        (void)attr;                                                                                            \
+        hipLaunchKernelGGL((k_ps_bwd_gemm<XTV, NCTV, NWV>), dim3(ntasks), dim3(NWV * 64), lds, st, vt, lists, counts, part, R, nT, nTp, H, W); \
+    }
+#define D2T_LAUNCH_PG_X(NCTV, NWV) { if (xt <= 4) D2T_LAUNCH_PG(4, NCTV, NWV) else if (xt <= 5) D2T_LAUNCH_PG(5, NCTV, NWV) else D2T_LAUNCH_PG(8, NCTV, NWV) }
+    D2T_LAUNCH_PG_X(2, 4)
+#undef D2T_LAUNCH_PG_X
+#undef D2T_LAUNCH_PG
+    rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    const int HW = H * W;
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
+    return launch_status();
+}
+
+// Which of the three backward designs runs (ps_bwd_design below).  History of the sorted lists vs the planes:
+// the sorted-corner-list kernels (d2t_pool_sorted.hip) do
 // work proportional to the RoI corners per plane (4R) plus a fixed cost of three launches and a
 // 49-workgroup sort; the plane kernels above walk every RoI's rows.  Measured crossover on MI355X
 // (38x75 map, R in 300..3000 x nT in 4..31, tools/ps_scan.py): the sorted design wins from 16 targets
 // up once R * nT reaches ~16000 (R=1000 nT=16: 68 vs 89 us; R=3000 nT=31: 158 vs 277 us) and loses
 // below 8 targets at every R (R=3000 nT=4: 94 vs 59 us).
-// D2T_PS_BWD=planes|sorted overrides the choice (a lab knob for that measurement, read once).
+// D2T_PS_BWD=planes|sorted|gemm overrides the choice (a lab knob for that measurement, read once).
 constexpr long long PS_SORTED_MIN_WORK = 14000;
 constexpr int PS_SORTED_MIN_TARGETS = 12;
 
@@ -838,35 +1067,47 @@ static int ps_bwd_forced()
     static const int v = [] {
         const char* e = getenv("D2T_PS_BWD");
         if (!e) return 0;
-        return !strcmp(e, "planes") ? 1 : !strcmp(e, "sorted") ? 2 : 0;
+        return !strcmp(e, "planes") ? 1 : !strcmp(e, "sorted") ? 2 : !strcmp(e, "gemm") ? 3 : 0;
     }();
     return v;
 }
 
-static bool ps_bwd_use_sorted(int R, int nT, int H, int W, int k)
+// 0 = plane kernels, 1 = sorted corner lists, 2 = GEMM
+static int ps_bwd_design(int R, int nT, int H, int W, int k)
 {
-    const bool s = psroipool_bwd_sorted_supported(R, nT, H, W, k), p = psroipool_bwd_planes_supported(R, nT, H, W, k);
-    if (!s || !p) return s;
+    const bool g = psroipool_bwd_gemm_supported(R, nT, H, W, k), s = psroipool_bwd_sorted_supported(R, nT, H, W, k),
+               p = psroipool_bwd_planes_supported(R, nT, H, W, k);
     const int f = ps_bwd_forced();
-    if (f) return f == 2;
-    return nT >= PS_SORTED_MIN_TARGETS && 1LL * R * nT >= PS_SORTED_MIN_WORK;
+    if (f == 3 && g) return 2;
+    if (f == 2 && s) return 1;
+    if (f == 1 && p) return 0;
+    // measured grid R in {300..3000} x nT in {4..31} on a 38x75 map (tools/ps_scan.py, profiles/r02_b_ps_bwd_scan_*):
+    // the GEMM wins from 12 targets up at every R (R=300 nT=16: 33 vs 40 us; R=3000 nT=31: 73 vs 148 sorted / 278 planes)
+    // and from 8 targets at R >= 1000; the plane kernels keep the small shapes (R=300 nT=4: 15 vs 25 us)
+    if (g && (nT >= 12 || (nT >= 8 && R >= 1000) || !p)) return 2;
+    if (s && (!p || (nT >= PS_SORTED_MIN_TARGETS && 1LL * R * nT >= PS_SORTED_MIN_WORK))) return 1;
+    return p ? 0 : (s ? 1 : 0);
 }
 
 bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
 {
-    return psroipool_bwd_sorted_supported(R, nT, H, W, k) || psroipool_bwd_planes_supported(R, nT, H, W, k);
+    return psroipool_bwd_gemm_supported(R, nT, H, W, k) || psroipool_bwd_sorted_supported(R, nT, H, W, k) ||
+           psroipool_bwd_planes_supported(R, nT, H, W, k);
 }
 
 size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
 {
-    return ps_bwd_use_sorted(R, nT, H, W, k) ? psroipool_bwd_sorted_ws_bytes(R, nT, H, W, k)
-                                             : psroipool_bwd_planes_ws_bytes(R, nT, H, W, k);
+    const int d = ps_bwd_design(R, nT, H, W, k);
+    return d == 2 ? psroipool_bwd_gemm_ws_bytes(R, nT, H, W, k) : d == 1 ? psroipool_bwd_sorted_ws_bytes(R, nT, H, W, k)
+                                                                         : psroipool_bwd_planes_ws_bytes(R, nT, H, W, k);
 }
 
 int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
                       void* ws, hipStream_t st)
 {
-    if (ps_bwd_use_sorted(R, nT, H, W, k)) return psroipool_bwd_sorted_f32(gout, rois, gin, R, nT, H, W, k, ws, st);
+    const int d = ps_bwd_design(R, nT, H, W, k);
+    if (d == 2) return psroipool_bwd_gemm_f32(gout, rois, gin, R, nT, H, W, ws, st);
+    if (d == 1) return psroipool_bwd_sorted_f32(gout, rois, gin, R, nT, H, W, k, ws, st);
     return psroipool_bwd_planes_f32(gout, rois, gin, R, nT, H, W, k, ws, st);
 }
 

@@ -90,7 +90,8 @@ def test_known_answer_fixture():
 CASES = [  # (R, nT, H, W, k)
     (3, 1, 10, 10, 6), (11, 3, 38, 63, 7), (11, 5, 9, 14, 3), (24, 4, 38, 75, 7), (300, 21, 38, 63, 7),
     (64, 31, 38, 75, 7), (5, 2, 11, 10, 7), (1, 1, 3, 3, 1), (130, 4, 20, 20, 5),
-    (1200, 13, 38, 75, 7), (1000, 16, 21, 30, 7),        # backward through the sorted corner lists (auto dispatch)
+    (1200, 13, 38, 75, 7), (1000, 16, 21, 30, 7),        # backward as a GEMM (auto dispatch from 12 targets up)
+    (260, 32, 9, 100, 7), (1100, 9, 38, 63, 7), (40, 33, 12, 20, 7),   # 32 targets x 7 column tiles; 8..11 targets at R >= 1000; 33 targets: not the GEMM
 ]
 
 
@@ -133,8 +134,8 @@ def test_matches_live_reference(case, ref_modules):
 
 
 def test_sorted_lists_backward_adversarial_rois(oracle):
-    """The sorted-corner-list backward (d2t_pool_sorted.hip; chosen from 12 targets and R*nT >= 14000 up)
-    on the adversarial RoIs -- clamped, empty, reversed and one-pixel bins -- repeated among random ones,
+    """The many-target backward designs (the GEMM form from 12 targets up; the sorted corner lists under
+    D2T_PS_BWD=sorted) on the adversarial RoIs -- clamped, empty, reversed and one-pixel bins -- repeated among random ones,
     so that equal corner addresses span many list steps."""
     from detect_to_track.models import _ext
     nT, H, W, k = 16, 38, 63, 7
