@@ -69,6 +69,8 @@ def _pool_cases():
     for _ in range(10):
         cases.append((int(rng.integers(1, 70)), int(rng.integers(1, 150)), int(rng.integers(1, 50)), int(rng.integers(1, 90))))
     cases += [(65, 64, 38, 63), (3, 65, 2, 130), (130, 1, 47, 5), (20, 300, 38, 75), (7, 33, 70, 70)]
+    # the backward's GEMM form serves maps up to 128 columns (4, 5 or 8 column tiles), the per-pixel kernel the wider ones
+    cases += [(10, 40, 12, 128), (9, 33, 10, 140), (257, 17, 1, 77), (300, 31, 3, 16), (1, 1, 1, 1)]
     return cases
 
 
@@ -95,6 +97,9 @@ def _ps_cases():
     for _ in range(10):
         cases.append((int(rng.integers(1, 90)), int(rng.integers(1, 8)), int(rng.integers(1, 50)), int(rng.integers(1, 90))))
     cases += [(300, 12, 38, 63), (5, 2, 64, 65), (64, 1, 60, 100), (129, 11, 38, 75)]       # incl. maps > 4096 pixels
+    for _ in range(8):                                                       # 12..32 targets: the backward's GEMM form
+        cases.append((int(rng.integers(1, 400)), int(rng.integers(12, 33)), int(rng.integers(1, 50)), int(rng.integers(1, 129))))
+    cases += [(1200, 9, 20, 30), (70, 33, 11, 40), (33, 20, 10, 140)]        # 8..11 targets at R >= 1000; beyond 32 targets / 128 columns: other designs
     return cases
 
 
