@@ -977,8 +977,8 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     D2T_WCLK_DECL(w_t0, w_t1, w_t2, w_t3, w_a, w_b, w_c, w_d, w_q = 0, w_put = 0, w_bar = 0, w_st = 0);
     D2T_WCLK(w_t0);
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // (role, b) pairs stay on one XCD
-    const int tj = bid % tiles_j, b = (bid / tiles_j) % B, role = bid / (tiles_j * B);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // both roles of a batch item stay on one XCD: they share gradOut[b]
+    const int tj = bid % tiles_j, role = (bid / tiles_j) & 1, b = bid / (2 * tiles_j);
     const int j0 = tj * TP, HW = H * W;
     const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
     const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);

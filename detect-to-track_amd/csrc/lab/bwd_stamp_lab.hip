@@ -49,7 +49,9 @@ int main(int argc, char** argv)
     for (int role = 0; role < 2; ++role) {
         std::vector<double> v[7], tot;
         for (int w = 0; w < blocks; ++w) {
-            if ((w / (tiles_j * B)) != role) continue;               // blockIdx.x -> xcd_remap changes the strip, not the count per role...
+            const int xcd = w & 7, qq = blocks >> 3, rr = blocks & 7;    // xcd_remap on the host, then the kernel's decode
+            const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (w >> 3);
+            if (((bid / tiles_j) & 1) != role) continue;
             for (int k = 0; k < ST_WAVES; ++k) {
                 const unsigned long long* p = &s[((size_t)w * ST_WAVES + k) * 8];
                 v[0].push_back((double)(p[1] - p[0])); v[1].push_back((double)(p[2] - p[1])); v[2].push_back((double)(p[3] - p[2]));
@@ -57,7 +59,7 @@ int main(int argc, char** argv)
                 tot.push_back((double)(p[3] - p[0]));
             }
         }
-        printf("blocks %d..%d (median over waves, cycles of s_memtime = 100 MHz x ? -- see total)\n", role * tiles_j * B, (role + 1) * tiles_j * B - 1);
+        printf("role %d (median over waves, shader clock cycles)\n", role);
         for (int k = 0; k < 7; ++k) printf("  %-44s %9.0f\n", names[k], med(v[k]));
         printf("  %-44s %9.0f\n", "wave total", med(tot));
     }
