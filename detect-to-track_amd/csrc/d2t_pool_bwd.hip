@@ -408,6 +408,8 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
                 for (int ct = 0; ct < NCT; ++ct) av[q][ct] = q < mine ? ga[ct][go] : 0.f;
             }
 #pragma unroll 1
+            // (a straight-line variant -- list padded so that every wave runs full prefetch rounds, loads unconditional --
+            // is what k_ps_bwd_gemm uses, where it gained 6 %; here it measured 92 us against 82 us for this form)
             for (int m0 = 0; m0 < mine; m0 += RG_PF) {
 #pragma unroll
                 for (int q = 0; q < RG_PF; ++q) {
@@ -918,7 +920,8 @@ k_ps_bwd_gemm(const float* __restrict__ vt, const PgPair* __restrict__ lists, co
 #pragma unroll
         for (int x = 0; x < XT; ++x) acc[ct][x] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int p0 = 0; p0 < cnt; p0 += PG_CH) {
-        const int pc = cnt - p0 < PG_CH ? cnt - p0 : PG_CH, nsl = (pc + 3) & ~3, nks = nsl >> 2;
+        const int pc = cnt - p0 < PG_CH ? cnt - p0 : PG_CH;
+        const int nksp = ((pc + 3) / 4 + NW * RG_PF - 1) / (NW * RG_PF) * (NW * RG_PF), nsl = 4 * nksp, nks = nksp;   // padded with zero-scale slots
         if (p0) __syncthreads();                                     // previous chunk consumed
         for (int e = tid; e < nsl; e += NTHR) {
             RmSlot sl{0, 0, 0.f, 0};
@@ -945,30 +948,29 @@ k_ps_bwd_gemm(const float* __restrict__ vt, const PgPair* __restrict__ lists, co
             for (int q = 0; q < 4; ++q) slots[4 * ks + q].pad = tm;
         }
         __syncthreads();
-        const int mine = (nks - wave + NW - 1) / NW;                 // wave w takes k-steps w, w+NW, ...
+        const int mine = nksp / NW;                                  // wave w takes k-steps w, w+NW, ... (padded: straight-line loop)
+        const RmSlot* my = slots + 4 * wave + g;
         float av[RG_PF][NCT];
 #pragma unroll
         for (int q = 0; q < RG_PF; ++q) {
-            const int go = q < mine ? slots[4 * (wave + NW * q) + g].goff : 0;
+            const int go = my[4 * NW * q].goff;
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) av[q][ct] = q < mine ? va[go + 16 * ct] : 0.f;
+            for (int ct = 0; ct < NCT; ++ct) av[q][ct] = va[go + 16 * ct];
         }
 #pragma unroll 1
         for (int m0 = 0; m0 < mine; m0 += RG_PF) {
 #pragma unroll
             for (int q = 0; q < RG_PF; ++q) {
-                const int m = m0 + q;
-                const RmSlot e = slots[4 * (wave + NW * (m < mine ? m : 0)) + g];
-                const float sc = m < mine ? e.scale : 0.f;
+                const RmSlot e = my[4 * NW * (m0 + q)];
                 float a[NCT];
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) a[ct] = sc != 0.f ? av[q][ct] * sc : 0.f;
-                const int nxt = m + RG_PF;
-                const int go = nxt < mine ? slots[4 * (wave + NW * nxt) + g].goff : 0;
+                for (int ct = 0; ct < NCT; ++ct) a[ct] = e.scale != 0.f ? av[q][ct] * e.scale : 0.f;
+                const int nxt = m0 + q + RG_PF < mine ? m0 + q + RG_PF : mine - 1;
+                const int go = my[4 * NW * nxt].goff;
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) av[q][ct] = nxt < mine ? va[go + 16 * ct] : 0.f;
-                const int j0 = sc != 0.f ? e.jb & 0xffff : 0, j1 = sc != 0.f ? e.jb >> 16 : 0;
-                const int tm = m < mine ? __builtin_amdgcn_readfirstlane(e.pad) : 0;
+                for (int ct = 0; ct < NCT; ++ct) av[q][ct] = va[go + 16 * ct];
+                const int j0 = e.jb & 0xffff, j1 = e.jb >> 16;
+                const int tm = __builtin_amdgcn_readfirstlane(e.pad);
 #pragma unroll
                 for (int x = 0; x < XT; ++x) {
                     if (!(tm & (1 << x))) continue;
