@@ -187,6 +187,32 @@ class HipDevice:
                                               c["B"], c["C"], c["H"], c["W"], c["d"], c["s"],
                                               self.wsb.data_ptr(), self.wsb_n, self.impl, self.sh))
 
+    def capture(self, order):
+        """The steps `order` (buffer-set indices) as ONE HIP graph: the C-ABI calls are asynchronous, allocate
+        nothing and keep no state, so a training loop can replay its steps without per-launch host work."""
+        torch = self.torch
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            saved, self.sh = self.sh, torch.cuda.current_stream(self.dev).cuda_stream   # launch on the capturing stream
+            try:
+                for z in order:
+                    self.fwd(z)
+                    self.bwd(z)
+            finally:
+                self.sh = saved
+        return graph
+
+    def replay(self, graph):
+        graph.replay()
+
+    def snapshot(self, i):
+        """Copies of the outputs of buffer set i (to compare a graph replay with eager launches)."""
+        z = self.sets[i]
+        return [z[k].clone() for k in ("out", "g0", "g1")]
+
+    def same(self, a, b):
+        return all(self.torch.equal(x, y) for x, y in zip(a, b))
+
     def synchronize(self):
         self.torch.cuda.synchronize(self.dev)
 
@@ -234,22 +260,45 @@ def run(args, device):
         device.bwd(i % n_sets)
 
     K = args.steps
+    order = [(args.warmup + i) % n_sets for i in range(K)]
+    # Timed region 1 (the metric): EXACTLY K steps replayed as one HIP graph between the barriers -- no host work
+    # between the kernels (eager launches + the event records below leave ~8 us of gaps in a 135 us step).
+    graph = device.capture(order) if args.graph and hasattr(device, "capture") else None
+    elapsed_graph = None
+    if graph is not None:
+        device.replay(graph)                                    # untimed: instantiation / first launch
+        device.synchronize()
+        if hasattr(device, "snapshot"):                         # the replay really ran the steps: its outputs are bit-identical
+            got = device.snapshot(order[-1])                    # to eager launches on the same buffers (deterministic kernels)
+            device.fwd(order[-1])
+            device.bwd(order[-1])
+            device.synchronize()
+            if not device.same(got, device.snapshot(order[-1])):
+                raise RuntimeError("graph replay and eager launches disagree")
+        barrier()
+        t0 = time.perf_counter()
+        device.replay(graph)
+        barrier()
+        elapsed_graph = time.perf_counter() - t0
+    # Timed region 2: the same K steps launched eagerly with HIP events on the launch stream around every
+    # kernel: the per-kernel durations of `kernels[]` / `roofline` (and the metric when --graph 0).
     ev = [device.new_event() for _ in range(3 * K)]
     barrier()
     t0 = time.perf_counter()
     for i in range(K):
-        z = (args.warmup + i) % n_sets
+        z = order[i]
         device.record(ev[3 * i])
         device.fwd(z)
         device.record(ev[3 * i + 1])
         device.bwd(z)
         device.record(ev[3 * i + 2])
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_eager = time.perf_counter() - t0
 
     us_fwd = [device.elapsed_ms(ev[3 * i], ev[3 * i + 1]) * 1e3 for i in range(K)]
     us_bwd = [device.elapsed_ms(ev[3 * i + 1], ev[3 * i + 2]) * 1e3 for i in range(K)]
-    elapsed = max_over_ranks(elapsed, world, device.reduce_device())
+    elapsed_eager = max_over_ranks(elapsed_eager, world, device.reduce_device())
+    elapsed = elapsed_eager if elapsed_graph is None else max_over_ranks(elapsed_graph, world, device.reduce_device())
 
     if rank == 0:
         ms = elapsed / K * 1e3
@@ -290,6 +339,9 @@ def run(args, device):
             "pct_hbm_roofline_fwd": 100 * kernels[0]["hbm"]["frac"],
             "pct_hbm_roofline_bwd": 100 * kernels[1]["hbm"]["frac"],
             "host_ms_per_step_minus_device": ms - t_dev,
+            "ms_per_step_eager": elapsed_eager / K * 1e3,
+            "timing": {"value": "one hipGraph replay of the K steps" if elapsed_graph is not None else "eager launches",
+                       "kernels": "HIP events on the launch stream, eager pass of the same K steps"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, cnt)
@@ -309,6 +361,7 @@ def parse_args(argv=None):
     ap.add_argument("--sets", type=int, default=0, help="rotated buffer sets (0 = enough for > 512 MiB)")
     ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 tuned only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="1: the timed K steps are one HIP graph replay; 0: eager launches")
     return ap.parse_args(argv)
 
 
