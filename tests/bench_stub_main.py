@@ -44,6 +44,16 @@ class CpuStub:
         self.calls["bwd"] += 1
         time.sleep(self.BWD_S * (1 + self.rank))
 
+    def capture(self, order):
+        """bench.run()'s graph branch: on the GPU one HIP graph of the K steps; here the list of steps."""
+        assert all(0 <= z < self.n_sets for z in order)
+        return list(order)
+
+    def replay(self, graph):
+        for z in graph:
+            self.fwd(z)
+            self.bwd(z)
+
     def synchronize(self):
         pass
 
@@ -65,6 +75,6 @@ if __name__ == "__main__":
     a.no_cpu_baseline = True
     stub = CpuStub()
     bench.run(a, stub)
-    n = stub.n_sets + a.warmup + a.steps
+    n = stub.n_sets + a.warmup + a.steps * (3 if a.graph else 1)   # graph mode: untimed replay + timed replay + eager event pass
     assert stub.calls == {"fwd": n, "bwd": n}, stub.calls
     print(f"stub rank {stub.rank} done", file=sys.stderr)
