@@ -925,7 +925,10 @@ __device__ __forceinline__ void strip_vec_put(float* __restrict__ rb, int role, 
 // pixel's own window.  Every poisoned element is itself non-finite, so a wave that stored a
 // non-finite value recomputes ITS region (16 channels x the strip) in the reference's own form at
 // the end of the kernel: gather loops, fused multiply-add chain, ascending order -- the same
-// arithmetic as the type-generic kernel.  Cold code: never runs on finite inputs.
+// arithmetic as the type-generic kernel.  Cold code: never runs on finite inputs.  The 16-wave kernel
+// repairs only the 4x4 tiles it stored a non-finite value for (one Inf in a feature map poisons the
+// tiles whose windows contain it, not the strip: a whole-strip repair took 12.6 ms per call when a
+// diverged model fed NaNs).
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ bool nonfinite4(const f32x4& d)
 {
@@ -936,11 +939,11 @@ __device__ __forceinline__ bool nonfinite4(const f32x4& d)
 
 __device__ __attribute__((noinline)) void strip_repair(int role, int lane, const float* __restrict__ gb,
                                                        const float* __restrict__ Sb, float* __restrict__ gxb,
-                                                       int cw, int C, int H, int W, int j0, int ps, int cs)
+                                                       int cw, int C, int H, int W, int j0, int ps, int cs, int y0, int y1)
 {
-    const int HW = H * W;
-    for (int e = lane; e < 16 * H * TP; e += 64) {
-        const int c = cw + e / (H * TP), rem = e % (H * TP), y = rem / TP, x = j0 + rem % TP;
+    const int HW = H * W, nr = y1 - y0;                              // map rows [y0, y1) of the strip
+    for (int e = lane; e < 16 * nr * TP; e += 64) {
+        const int c = cw + e / (nr * TP), rem = e % (nr * TP), y = y0 + rem / TP, x = j0 + rem % TP;
         if (c >= C || x >= W) continue;
         const float* sc = Sb + (size_t)c * HW;
         float a = 0.f;
@@ -1001,11 +1004,11 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
         rho = rho < H ? rho : H - 1;
         return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
     };
-    bool bad = false;                                                // this lane stored a non-finite value
+    unsigned long long badt = 0;                                     // tiles this lane stored a non-finite value for (bit u mod 64)
     auto store_tile = [&](const f32x4& d, int u) {
         const int i = 4 * u + (n >> 2), j = j0 + (n & 3);
         if (u < 0 || u >= tiles_i || i >= H || j >= W) return;
-        bad = bad || nonfinite4(d);
+        badt |= nonfinite4(d) ? 1ull << (u & 63) : 0ull;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = cw + 4 * g + r;
@@ -1117,8 +1120,20 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
         o[0] = w_t0; o[1] = w_t1; o[2] = w_t2; o[3] = w_t3; o[4] = w_q; o[5] = w_put; o[6] = w_bar; o[7] = w_st;
     }
 #endif
-    if (__builtin_expect(__any(bad), 0))                             // cold: non-finite inputs only
-        strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs);
+    if (__builtin_expect(__any(badt != 0), 0)) {                     // cold: non-finite inputs only
+        unsigned lo = (unsigned)badt, hi = (unsigned)(badt >> 32);
+#pragma unroll
+        for (int off = 32; off; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
+        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+        if (tiles_i > 64) {
+            strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs, 0, H);
+        } else {
+            for (int u = 0; u < tiles_i; ++u)
+                if ((m >> u) & 1)
+                    strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs,
+                                 4 * u, 4 * u + 4 < H ? 4 * u + 4 : H);
+        }
+    }
 }
 
 // The same kernel with the workgroup width as a template parameter (instantiated for 4 waves = 64
@@ -1241,7 +1256,7 @@ k_corr_bwd_strip_n(BwdLevels lv, int B, int H, int W, int tiles_i, int tiles_j, 
         store_tile(acc[0], tiles_i - 2);                             // their remaining super-steps lie below the map
         store_tile(acc[1], tiles_i - 1);
         if (__builtin_expect(__any(bad), 0))                         // cold: non-finite inputs only
-            strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs);
+            strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs, 0, H);
     }
 }
 
