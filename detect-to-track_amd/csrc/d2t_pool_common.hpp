@@ -46,8 +46,10 @@ inline size_t prefix_scratch_bytes(int nb, int H, int W)
     return (size_t)nb * ((size_t)H * ((W + PX_SEG - 1) / PX_SEG) + (size_t)((H + PY_SEG - 1) / PY_SEG) * W) * 8;
 }
 
+// es: doubles between horizontally adjacent elements of one map (1: planar maps; nb with mstride = 1: maps
+// interleaved element by element).
 __device__ __forceinline__ void prefix2d(double* __restrict__ F, double* __restrict__ scr, int nb, int H, int W, int LDW,
-                                         int mstride /* doubles between maps */, int tid, int nthr)
+                                         int mstride /* doubles between maps */, int tid, int nthr, int es = 1)
 {
     const int nsx = (W + PX_SEG - 1) / PX_SEG, nsy = (H + PY_SEG - 1) / PY_SEG;
     const int ntx = nb * H * nsx;
@@ -58,11 +60,11 @@ __device__ __forceinline__ void prefix2d(double* __restrict__ F, double* __restr
         const int t = t0 + tid;
         const bool on = t < ntx;
         const int row = on ? t / nsx : 0, sg = on ? t - row * nsx : 0, bb = row / H, y = row - bb * H;
-        double* p = F + (size_t)bb * mstride + y * LDW + sg * PX_SEG;
+        double* p = F + (size_t)bb * mstride + (size_t)(y * LDW + sg * PX_SEG) * es;
         const int len = W - sg * PX_SEG < PX_SEG ? W - sg * PX_SEG : PX_SEG;
         double v[PX_SEG];
 #pragma unroll
-        for (int k = 0; k < PX_SEG; ++k) v[k] = on && k < len ? p[k] : 0.0;
+        for (int k = 0; k < PX_SEG; ++k) v[k] = on && k < len ? p[k * es] : 0.0;
 #pragma unroll
         for (int k = 1; k < PX_SEG; ++k) v[k] += v[k - 1];
         if (on) scr[t] = v[PX_SEG - 1];
@@ -71,7 +73,7 @@ __device__ __forceinline__ void prefix2d(double* __restrict__ F, double* __restr
         for (int s2 = 0; s2 < sg; ++s2) off += scr[row * nsx + s2];
 #pragma unroll
         for (int k = 0; k < PX_SEG; ++k)
-            if (on && k < len) p[k] = v[k] + off;
+            if (on && k < len) p[k * es] = v[k] + off;
         __syncthreads();
     }
     // along y the same way; consecutive threads own consecutive columns
@@ -81,11 +83,11 @@ __device__ __forceinline__ void prefix2d(double* __restrict__ F, double* __restr
         const int t = t0 + tid;
         const bool on = t < nty;
         const int bs = on ? t / W : 0, x = on ? t - bs * W : 0, bb = bs / nsy, sg = bs - bb * nsy;
-        double* p = F + (size_t)bb * mstride + (size_t)sg * PY_SEG * LDW + x;
+        double* p = F + (size_t)bb * mstride + ((size_t)sg * PY_SEG * LDW + x) * es;
         const int len = H - sg * PY_SEG < PY_SEG ? H - sg * PY_SEG : PY_SEG;
         double v[PY_SEG];
 #pragma unroll
-        for (int k = 0; k < PY_SEG; ++k) v[k] = on && k < len ? p[k * LDW] : 0.0;
+        for (int k = 0; k < PY_SEG; ++k) v[k] = on && k < len ? p[(size_t)k * LDW * es] : 0.0;
 #pragma unroll
         for (int k = 1; k < PY_SEG; ++k) v[k] += v[k - 1];
         if (on) scy[t] = v[PY_SEG - 1];
@@ -94,7 +96,7 @@ __device__ __forceinline__ void prefix2d(double* __restrict__ F, double* __restr
         for (int s2 = 0; s2 < sg; ++s2) off += scy[(bb * nsy + s2) * W + x];
 #pragma unroll
         for (int k = 0; k < PY_SEG; ++k)
-            if (on && k < len) p[k * LDW] = v[k] + off;
+            if (on && k < len) p[(size_t)k * LDW * es] = v[k] + off;
         __syncthreads();
     }
 }
