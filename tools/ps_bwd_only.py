@@ -7,8 +7,8 @@ from detect_to_track.models import _native
 from bench_ops import random_rois, timed, _ws
 L = _native.lib
 dev = "cuda:0"; st = torch.cuda.current_stream().cuda_stream
-k, H, W, R = 7, 38, 75, 3000
-for nT in (31, 4):
+k, H, W, R = 7, 38, 63, 300
+for nT in (21,):
     go = [torch.rand(R, nT, k, k, device=dev) for _ in range(3)]
     gin = [torch.empty(nT * 49, H, W, device=dev) for _ in range(3)]
     rois = torch.from_numpy(random_rois(R, 1)).to(dev)
