@@ -20,7 +20,11 @@ for it in range(N):
             a, b = _ext.roipool_forward(fm, rois, 7, TUNED), _ext.roipool_forward(fm, rois, 7, GENERIC)
             assert torch.equal(a.isnan(), b.isnan())
             torch.testing.assert_close(torch.nan_to_num(a), torch.nan_to_num(b), **TOL)
-            torch.testing.assert_close(_ext.roipool_backward(gout, rois, H, W, TUNED), _ext.roipool_backward(gout, rois, H, W, GENERIC), rtol=2e-5, atol=2e-5)
+            # gradients are sums of thousands of signed f32 terms in kernel-specific orders: the yardstick is
+            # f32 rounding of the sum of their MAGNITUDES (the backward of |gradOut|), not of the result
+            t, g = _ext.roipool_backward(gout, rois, H, W, TUNED), _ext.roipool_backward(gout, rois, H, W, GENERIC)
+            mag = _ext.roipool_backward(gout.abs(), rois, H, W, GENERIC)
+            assert bool(((t - g).abs() <= 4e-6 * mag + 1e-6).all()), f"max excess {float(((t - g).abs() - 4e-6 * mag).max())}"
         except Exception as e:
             bad += 1; print("ROIPOOL FAIL", (R, C, H, W), str(e)[:300], flush=True)
     else:
@@ -30,7 +34,9 @@ for it in range(N):
         rois = _rois(rng, R)
         try:
             assert torch.equal(_ext.ps_roipool_forward(fm, rois, nT, 7, TUNED), _ext.ps_roipool_forward(fm, rois, nT, 7, GENERIC))
-            torch.testing.assert_close(_ext.ps_roipool_backward(gout, rois, H, W, TUNED), _ext.ps_roipool_backward(gout, rois, H, W, GENERIC), rtol=2e-5, atol=2e-5)
+            t, g = _ext.ps_roipool_backward(gout, rois, H, W, TUNED), _ext.ps_roipool_backward(gout, rois, H, W, GENERIC)
+            mag = _ext.ps_roipool_backward(gout.abs(), rois, H, W, GENERIC)
+            assert bool(((t - g).abs() <= 4e-6 * mag + 1e-6).all()), f"max excess {float(((t - g).abs() - 4e-6 * mag).max())}"
         except Exception as e:
             bad += 1; print("PSROIPOOL FAIL", (R, nT, H, W), str(e)[:300], flush=True)
     if it % 25 == 24: print(f"{it + 1} cases, {bad} failures", flush=True)
