@@ -1,0 +1,27 @@
+"""dev helper: long randomised sweep of the correlation kernels, tuned vs generic (forward bit-exact, gradients
+against the f32 rounding of the sum of term magnitudes)."""
+import sys, numpy as np, torch
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
+from detect_to_track.models import _ext
+GENERIC, TUNED = 1, 2
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = 0
+for it in range(N):
+    B = int(rng.integers(1, 10)); C = int(rng.integers(1, 300)); H = int(rng.integers(1, 50)); W = int(rng.integers(20, 100))
+    g = torch.Generator(device="cpu").manual_seed(it * 7919 + 13)
+    fm0 = (torch.rand(B, C, H, W, generator=g) - 0.5).cuda(); fm1 = (torch.rand(B, C, H, W, generator=g) - 0.5).cuda()
+    go = torch.randn(B, H, W, 17, 17, generator=g).cuda()
+    try:
+        a, b = _ext.pointwise_correlation_forward(fm0, fm1, 8, 1, TUNED), _ext.pointwise_correlation_forward(fm0, fm1, 8, 1, GENERIC)
+        assert torch.equal(a, b), f"forward max |delta| {float((a - b).abs().max())}"
+        t0, t1 = _ext.pointwise_correlation_backward(go, fm0, fm1, 8, 1, TUNED)
+        g0, g1 = _ext.pointwise_correlation_backward(go, fm0, fm1, 8, 1, GENERIC)
+        m0, m1 = _ext.pointwise_correlation_backward(go.abs(), fm0.abs(), fm1.abs(), 8, 1, GENERIC)
+        assert bool(((t0 - g0).abs() <= 4e-6 * m0 + 1e-7).all()) and bool(((t1 - g1).abs() <= 4e-6 * m1 + 1e-7).all())
+    except Exception as e:
+        bad += 1; print("CORR FAIL", (B, C, H, W), str(e)[:200], flush=True)
+    if it % 20 == 19: print(f"{it + 1} cases, {bad} failures", flush=True)
+print("done", N, "cases,", bad, "failures")
