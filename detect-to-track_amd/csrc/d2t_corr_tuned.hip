@@ -21,7 +21,7 @@
 //   k_corr_fwd_segx<2,4>  2 tiles /  6 waves, ring of 4 chunks    (medium grids)
 //   k_corr_fwd_segx<1,4>  1 tile  /  3 waves, ring of 4 chunks    (the real model's B = 1 pairs)
 // The epilogue stages the segment's outputs (including the structural zeros the reference gets
-// from at::zeros, :192) in LDS and stores contiguous runs with write-through stores.  The XCD-aware
+// from at::zeros, :192) in LDS and stores contiguous 16-byte runs.  The XCD-aware
 // block map gives every XCD a contiguous run of segments so that neighbours share L2 lines.
 // The first generation (one p-tile per workgroup, FM1 gathered straight from L2) measured
 // texture-address-bound and is gone; DESIGN.md section 4.2 keeps its numbers.
@@ -432,7 +432,8 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
         const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
-                                               ro, off, 0, 16);     // aux 16 = sc1 (write-through)
+                                               ro, off, 0, 0);     // plain write-back stores.  Round 1 used sc1 (write-through: 63 -> 51 us
+                                                                   // then); with the ring-of-3 schedule plain stores are 0.9 us faster (A/B, round 2)
     }
     const int tail = run_ - 4 * run4;                                // 0..3 floats per pixel row (nj < 4)
     for (int e = tid; e < prs * tail; e += SG_THREADS) {
