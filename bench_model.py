@@ -55,6 +55,8 @@ def parse_args(argv=None):
     p.add_argument("--gpus", type=int, default=1, help="ranks (BASELINE config 5); launch with torch.distributed.run, one rank per GPU")
     p.add_argument("--bucket-mb", type=float, default=64.0, help="gradient all-reduce bucket size")
     p.add_argument("--backend", default="nccl", help="nccl = RCCL (one GPU per rank); gloo lets several ranks rehearse on ONE GPU")
+    p.add_argument("--miopen-find", action="store_true", help="let MIOpen benchmark its convolution algorithms (torch.backends.cudnn.benchmark): "
+                   "a long first step, faster library convolutions afterwards")
     return p.parse_args(argv)
 
 
@@ -121,6 +123,16 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
+        import threading
+        stop = threading.Event()
+
+        def heartbeat():                                                           # the algorithm search is silent for minutes
+            t0 = time.time()
+            while not stop.wait(45):
+                print(f"[bench_model] MIOpen find in progress, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+        threading.Thread(target=heartbeat, daemon=True).start()
     torch.manual_seed(0)                                                           # identical initial weights on every rank
     timer = OpTimer(_ext)
     # cfg/default.yaml: resnet50, first trainable stage 3, 5 areas x 3 ratios = 15 anchors, 30 classes, k = 7, d_max = 8
@@ -248,7 +260,7 @@ def main(argv=None):
     line = {
         "bench": "DetectTrack training step (BASELINE config %d)" % (4 if world == 1 else 5), "n_gpus": world, "scaling": "weak",
         "parallelism": f"dp{world}" if world > 1 else "single", "dtype": "f32", "data": "synthetic",
-        "weights": "random", "steps": args.steps, "warmup": args.warmup,
+        "weights": "random", "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find),
         "config": {"workload": f"detecttrack_{args.backbone}_B{B}pairs_3x{H}x{W}", "pairs": B, "frame": [3, H, W],
                    "c4": [fh, fw], "regions_per_frame": R, "tracked_boxes": Rt, "anchors": n_anchor},
         "ms_per_step": step_ms, "pairs_per_s": world * B / step_ms * 1e3, "pairs_per_gpu": B, "finite": finite, "max_abs_activation": amax,
