@@ -1003,6 +1003,7 @@ k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, 
         const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
         int rho = 4 * ss + xr;
         rho = rho < H ? rho : H - 1;
+        if (D2T_ABL & 8) rho = 0;                                    // (lab: every k-block re-reads map row 0 -- same instructions, ~10x fewer distinct lines)
         return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
     };
     unsigned long long badt = 0;                                     // tiles this lane stored a non-finite value for (bit u mod 64)
