@@ -77,7 +77,7 @@ int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int 
         if (ws_bytes < tuned::corr_fwd_ws_bytes(B, C, H, W, d, stride)) return D2T_EWS;
         return tuned::corr_fwd_f32(fm0, fm1, out, B, C, H, W, d, stride, ws, as_stream(stream));
     }
-    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;     // tuned path demanded but not applicable
+    if (impl == D2T_IMPL_MFMA || impl == D2T_IMPL_MFMA_STRIP16) return D2T_EINVAL;     // tuned path demanded but not applicable
     return corr_fwd_generic<float>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -86,7 +86,7 @@ int d2t_corr_fwd_f64(const double* fm0, const double* fm1, double* out, int B, i
 {
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
-    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (impl == D2T_IMPL_MFMA || impl == D2T_IMPL_MFMA_STRIP16) return D2T_EINVAL;
     return corr_fwd_generic<double>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -99,9 +99,10 @@ int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, floa
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
     if (impl != D2T_IMPL_GENERIC && tuned::corr_bwd_supported(B, C, H, W, d, stride)) {
         if (ws_bytes < tuned::corr_bwd_ws_bytes(B, C, H, W, d, stride)) return D2T_EWS;
-        return tuned::corr_bwd_f32(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, ws, as_stream(stream));
+        return tuned::corr_bwd_f32(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, ws, as_stream(stream),
+                                   impl == D2T_IMPL_MFMA_STRIP16);
     }
-    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (impl == D2T_IMPL_MFMA || impl == D2T_IMPL_MFMA_STRIP16) return D2T_EINVAL;
     return corr_bwd_generic<float>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -112,7 +113,7 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1, d
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
-    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (impl == D2T_IMPL_MFMA || impl == D2T_IMPL_MFMA_STRIP16) return D2T_EINVAL;
     return corr_bwd_generic<double>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -144,7 +145,7 @@ int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* 
     bool tuned_ok = impl != D2T_IMPL_GENERIC;
     for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_fwd_supported(B, C[l], H, W, d, stride);
     if (tuned_ok) return tuned::corr_fwd_levels_f32(n, fm0, fm1, out, C, B, H, W, lay, as_stream(stream));
-    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (impl == D2T_IMPL_MFMA || impl == D2T_IMPL_MFMA_STRIP16) return D2T_EINVAL;
     for (int l = 0; l < n; ++l) {
         rc = corr_fwd_generic<float>(fm0[l], fm1[l], out[l], B, C[l], H, W, d, stride, as_stream(stream), lay.ps, lay.cs, lay.bs);
         if (rc != D2T_OK) return rc;
@@ -167,8 +168,9 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
                                                                      : tuned::CellLayout{cells, 1, 1LL * HW * cells};
     bool tuned_ok = impl != D2T_IMPL_GENERIC;
     for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_bwd_supported(B, C[l], H, W, d, stride);
-    if (tuned_ok) return tuned::corr_bwd_levels_f32(n, gout, fm0, fm1, gfm0, gfm1, C, B, H, W, lay, as_stream(stream));
-    if (impl == D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (tuned_ok) return tuned::corr_bwd_levels_f32(n, gout, fm0, fm1, gfm0, gfm1, C, B, H, W, lay, as_stream(stream),
+                                                    impl == D2T_IMPL_MFMA_STRIP16);
+    if (impl == D2T_IMPL_MFMA || impl == D2T_IMPL_MFMA_STRIP16) return D2T_EINVAL;
     for (int l = 0; l < n; ++l) {
         rc = corr_bwd_generic<float>(gout[l], fm0[l], fm1[l], gfm0[l], gfm1[l], B, C[l], H, W, d, stride, as_stream(stream),
                                      lay.ps, lay.cs, lay.bs);

@@ -1,0 +1,368 @@
+// d2t_corr_bwd8.hip -- gfx950 f32 PointwiseCorrelation backward, 8-wave column-strip kernel
+// (d_max = 8, stride 1, reference layout).  Gather form of pointwise_correlation_cuda.cu:145-171:
+//     gX[c][t] = sum over window slots w of  G[t][w] * S[c][w]
+// role 0 (gradFM0): t = centre pixels, S = FM1;  role 1 (gradFM1): t = displaced pixels, S = FM0;
+// G = gradOut[b,i,j,di-i+d,dj-j+d] where the reference's loops visit that cell, else 0.  No atomics,
+// every output element written once, fixed summation order.
+//
+// Same strip walk as k_corr_bwd_strip (d2t_corr_tuned.hip: one workgroup = (role, batch item, strip
+// of 4 pixel columns, 256 channels), super-step = 4 map rows = 5 k-blocks of 16 window slots, 5
+// tiles alive), rebuilt around what the round-2 instruments showed about that kernel:
+//   * it sat at its 128-VGPR cap (16 waves), so the feature (S) fragment of a k-block was requested
+//     less than one k-block before its MFMAs and every k-block opened with `s_waitcnt vmcnt(0)`:
+//     the L2 round trip under load (1-2 us) was exposed 50 times per strip;
+//   * all 16 waves produced G, stored tiles and hit the barrier at the same moment, with the matrix
+//     pipe idle meanwhile.
+// Here a workgroup is 8 waves of up to 256 VGPRs, a wave owns TWO c-tiles (32 channels):
+//   * S fragments live in a static 5-entry register file a4[q][ct]: the piece of k-block q is
+//     re-requested for the NEXT super-step as soon as its last MFMA has been issued -- a prefetch
+//     distance of a whole super-step (about 5 us), through buffer loads whose range check returns
+//     zeros for channels >= C (no clamps, no 64-bit address arithmetic);
+//   * a G fragment read from LDS feeds both c-tiles (half the LDS read traffic per MFMA) and is
+//     fetched one k-block ahead (two static register sets that swap roles every super-step);
+//   * the one barrier of a super-step sits in front of its LAST k-block, whose G fragments are in
+//     registers by then: barrier latency and the first LDS round trip of the next super-step hide
+//     behind 40 MFMAs;
+//   * G production (ring writes of super-step s+1, requests for s+2) and the tile stores are
+//     spread over the k-blocks of a super-step instead of forming a burst at its end.
+#include "d2t_corr_common.hpp"
+#include <type_traits>
+
+namespace d2t { namespace tuned {
+
+namespace {
+
+constexpr int S8_WAVES = 8;
+constexpr int S8_THREADS = S8_WAVES * 64;
+constexpr int S8_CT = 2;                            // c-tiles (16 channels) per wave
+constexpr int S8_CH = S8_WAVES * S8_CT * 16;        // 256 channels per workgroup
+constexpr int S8_QUADS = KB_SS * NACT * 64;         // 1600 ring quads per super-step: [k-block][live tile][lane]
+constexpr int S8_NQ = (S8_QUADS + S8_THREADS - 1) / S8_THREADS;   // 4 per thread (the 4th only in wave 0)
+constexpr int S8_RING = S8_NQ * S8_THREADS * 4;     // floats per ring buffer (32 KB)
+constexpr int S8_OOR = 0x7ffffff0;                  // byte offset that every buffer range check rejects
+
+// One ring quad (k-block q of a super-step, live tile a, lane l) as a 16-byte run of gradOut: component c
+// is cell cj + c of row ci of one centre pixel (role 0: the four cells feed four consecutive window
+// slots of one tile pixel; role 1: one slot of four consecutive tile pixels, see g_put).
+// off: byte offset of the run at super-step 0 (may be negative; only used for lo <= ss < hi);
+// info: lo | hi << 8 | mask << 16, mask bit c = the reference's loops visit cell cj + c.  A run may
+// start left of cell 0 or end right of cell 15 of its row: it then covers cells of the neighbouring
+// row or pixel, inside gradOut[b] all the same (the first pixel's first row never starts left of cell 0,
+// the last pixel's row 15 never ends past cell 288), and those components are masked off.
+struct Quad8 { int off, info; };
+
+__device__ __forceinline__ Quad8 quad8_desc(int role, int e, int H, int W, int tiles_i, int j0, int col0)
+{
+    const int q = e / (NACT * 64), r = e - q * (NACT * 64);
+    const int a = r >> 6, l = r & 63, gg = l >> 4;
+    const int x = 4 * q + gg, xr = (x * 13) >> 6, cg = x - xr * NCG;      // x / 5, x % 5 (x < 32)
+    const int tpi = (l >> 2) & 3, lo2 = l & 3;                             // role 0: lo2 = tile column; role 1: slot column s
+    const int ci = role ? 4 * a + tpi - xr : xr - 4 * a - tpi + 2 * DT;    // displaced - centre + d (constant)
+    const int tj = j0 + lo2, sj = col0 + 4 * cg + (role ? lo2 : 0);
+    const int cj = role ? j0 - sj + DT : sj - tj + DT;                     // component c reads cell cj + c
+    int mask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool col_ok = role ? j0 + c < W : tj < W;
+        mask |= (cj + c >= 0 && cj + c < 2 * DT && col_ok) ? (1 << c) : 0;
+    }
+    if (ci < 0 || ci >= 2 * DT || e >= S8_QUADS) mask = 0;
+    const int pix0 = role ? xr * W + sj : (4 * (a - 2) + tpi) * W + tj;    // centre pixel at ss = 0
+    int lo = 2 - a, hi = tiles_i + 2 - a;
+    const int hi_t = (H - tpi + 3) / 4 + 2 - a;                            // 4(ss-2+a)+tpi < H
+    const int hi_r = (H - xr + 3) / 4;                                     // 4ss+xr < H
+    hi = hi < hi_t ? hi : hi_t;
+    hi = hi < hi_r ? hi : hi_r;
+    lo = lo < 0 ? 0 : lo;
+    if (!mask || hi < lo) { lo = 0; hi = 0; }
+    Quad8 d;
+    d.off = (pix0 * CELLS + ci * CW + cj) * 4;
+    d.info = lo | (hi << 8) | (mask << 16);
+    return d;
+}
+
+// unvisited cells -> exact zeros.  Bit arithmetic on purpose (v_bfe_i32 + v_and): compares would be
+// hoisted out of the strip loop into 16 SGPR pairs, and the kernel needs its SGPRs for three buffer
+// descriptors (a descriptor that ends up in VGPRs turns every buffer access into a waterfall loop).
+__device__ __forceinline__ f32x4 quad8_fix(const f32x4& v, int info)
+{
+    const u32x4 b = __builtin_bit_cast(u32x4, v);
+    u32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = b[c] & (unsigned)__builtin_amdgcn_sbfe(info, 16 + c, 1);
+    return __builtin_bit_cast(f32x4, o);
+}
+
+typedef std::integral_constant<int, 0> I0;
+typedef std::integral_constant<int, 1> I1;
+typedef std::integral_constant<int, 2> I2;
+typedef std::integral_constant<int, 3> I3;
+typedef std::integral_constant<int, 4> I4;
+typedef std::integral_constant<int, 5> I5;
+
+#define D2T_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// The strip walk for one role (compile-time: the two roles differ in the ring write pattern and in which
+// k-block of a tile is structurally zero; a run-time role splits the pinned schedule into many basic blocks).
+template <int role>
+__device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const float* __restrict__ gout,
+                                            const float* __restrict__ fm0, const float* __restrict__ fm1,
+                                            float* __restrict__ g0, float* __restrict__ g1,
+                                            int b, int tj, int C, int H, int W, int tiles_i)
+{
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = tj * TP, HW = H * W;
+    const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
+    const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
+    const float* S = (role ? fm0 : fm1) + (size_t)b * C * HW;
+    float* gx = (role ? g1 : g0) + (size_t)b * C * HW;
+    const float* gb = gout + (size_t)b * HW * CELLS;
+    const unsigned plane_bytes = (unsigned)C * HW * 4u;
+    const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(S, plane_bytes);
+    const __amdgpu_buffer_rsrc_t rx = uniform_rsrc(gx, plane_bytes);
+    const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(gb, (unsigned)HW * CELLS * 4u);
+
+    const int cw = blockIdx.y * S8_CH + wave * (S8_CT * 16);          // first channel of this wave's two c-tiles
+    // S piece of k-block q at super-step 0, c-tile 0 (bytes): lane (channel n, slot group 4q+g).  Channels
+    // >= C lie behind the buffer: zeros.  Rows >= H (last super-step) read the next plane: their G is 0.
+    int sv[KB_SS];
+#pragma unroll
+    for (int q = 0; q < KB_SS; ++q) {
+        const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
+        sv[q] = ((cw + n) * HW + xr * W + col0 + 4 * cg) * 4;
+    }
+    const int s_step = 4 * W * 4, ct_step = 16 * HW * 4;
+    auto s_load = [&](int ss, int q, int ct) -> f32x4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, sv[q] + ss * s_step + ct * ct_step, 0, 0);
+        return __builtin_bit_cast(f32x4, v);
+    };
+
+    // ---- G production: this thread's ring quads e = tid + 512 k
+    Quad8 qd[S8_NQ];
+#pragma unroll
+    for (int k = 0; k < S8_NQ; ++k) qd[k] = quad8_desc(role, tid + k * S8_THREADS, H, W, tiles_i, j0, col0);
+    // (quads 1600..2047 do not exist: their descriptors are empty -- an out-of-range request, zeros into ring
+    // slots nobody reads -- so that G production stays branch-free)
+    const int g_step = 4 * W * CELLS * 4;                            // gradOut bytes per 4 map rows
+    auto g_load = [&](int k, int ss) -> f32x4 {
+        const int lo = qd[k].info & 255, hi = (qd[k].info >> 8) & 255;
+        const int v = ss >= lo && ss < hi ? qd[k].off + ss * g_step : S8_OOR;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, v, 0, 0));
+    };
+    auto g_put = [&](float* rb, int k, const f32x4& raw) {
+        const f32x4 v = quad8_fix(raw, qd[k].info);
+        const int e = tid + k * S8_THREADS;
+        if (!role) { reinterpret_cast<f32x4*>(rb)[e] = v; return; }
+        // role 1: component lo2 = s of the quads of lanes (tpi*4 + c, gg), c = 0..3
+        float* w = rb + (((e & ~63) + (lane & 0x3c)) << 2) + (lane & 3);
+        w[0] = v[0]; w[4] = v[1]; w[8] = v[2]; w[12] = v[3];
+    };
+    f32x4 gn[S8_NQ];
+    auto g_load_all = [&](int ss) {
+#pragma unroll
+        for (int k = 0; k < S8_NQ; ++k) gn[k] = g_load(k, ss);
+    };
+    auto g_put_all = [&](float* rb) {
+#pragma unroll
+        for (int k = 0; k < S8_NQ; ++k) g_put(rb, k, gn[k]);
+    };
+
+    // ---- tile stores: lane (pixel n, channels 4g..4g+3 of each c-tile)
+    unsigned long long badt = 0;                                     // tiles this lane stored a non-finite value for (bit u mod 64)
+    const int x_lane = ((cw + 4 * g) * HW + (n >> 2) * W + j0 + (n & 3)) * 4;
+    const bool col_ok = j0 + (n & 3) < W;
+    auto store_tile = [&](const f32x4 (&d)[S8_CT], int u) {
+        if (u < 0 || u >= tiles_i) return;                           // wave-uniform
+        const int i = 4 * u + (n >> 2);
+        const int base = col_ok && i < H ? x_lane + 4 * u * W * 4 : S8_OOR;
+        badt |= (nonfinite4(d[0]) || nonfinite4(d[1])) && base != S8_OOR ? 1ull << (u & 63) : 0ull;
+#pragma unroll
+        for (int ct = 0; ct < S8_CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = d[ct][r];                            // (a bit_cast of the element lvalue d[ct][r] reads element 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rx,
+                                                      base == S8_OOR ? S8_OOR : base + ct * ct_step + r * HW * 4, 0, 0);
+            }
+    };
+
+    f32x4 acc[S8_CT][NACT], a4[KB_SS][S8_CT], done[S8_CT];
+#pragma unroll
+    for (int ct = 0; ct < S8_CT; ++ct) {
+        done[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) acc[ct][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- prologue: S pieces of super-step 0, ring[0] <- G(0), registers <- G(1)
+#pragma unroll
+    for (int q = 0; q < KB_SS; ++q)
+#pragma unroll
+        for (int ct = 0; ct < S8_CT; ++ct) a4[q][ct] = s_load(0, q, ct);
+    g_load_all(0);
+    g_put_all(ring[0]);
+    g_load_all(1);
+    lds_barrier();
+
+    const f32x4* lane_ring = reinterpret_cast<const f32x4*>(&ring[0][0]) + lane;
+    f32x4 bvP[NACT], bvQ[NACT];
+    auto b_fetch = [&](f32x4 (&bv)[NACT], int buf, int q, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#pragma unroll
+        for (int a = LO; a < HI; ++a) bv[a] = lane_ring[buf * (S8_RING / 4) + (q * NACT + a) * 64];
+    };
+
+    // One super-step.  bvC holds the G fragments of its k-block 0 on entry, bvN is free; on exit the roles are
+    // swapped (bvN holds k-block 0 of the next super-step).  LO/HI: live accumulators [LO, HI) -- the first two
+    // super-steps carry tiles -2/-1 in acc[0..1], the last two carry tiles past the map in acc[3..4]; NLO/NHI:
+    // the live range of the NEXT super-step (for the fragments fetched behind the barrier).
+    auto super_step = [&](int ss, f32x4 (&bvC)[NACT], f32x4 (&bvN)[NACT], auto lo_c, auto hi_c, auto nlo_c, auto nhi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        const int cur = ss & 1;
+        auto mfma = [&](const f32x4 (&bv)[NACT], int q, int s_lo, int s_hi) {
+            // One k-block of a tile's 25 is structurally zero: for role 0 the last one of its oldest live tile,
+            // for role 1 the first one of its newest; those go behind a wave-uniform branch.
+            const int A0 = (q == KB_SS - 1 && LO == 0) ? 1 : LO;
+            const int A1 = (q == 0 && HI == NACT) ? NACT - 1 : HI;
+#pragma unroll
+            for (int s = s_lo; s < s_hi; ++s)
+#pragma unroll
+                for (int a = A0; a < A1; ++a)
+#pragma unroll
+                    for (int ct = 0; ct < S8_CT; ++ct) acc[ct][a] = D2T_MFMA(a4[q][ct][s], bv[a][s], acc[ct][a]);
+            if (A0 != LO && role) {
+#pragma unroll
+                for (int s = s_lo; s < s_hi; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < S8_CT; ++ct) acc[ct][LO] = D2T_MFMA(a4[q][ct][s], bv[LO][s], acc[ct][LO]);
+            }
+            if (A1 != HI && !role) {
+#pragma unroll
+                for (int s = s_lo; s < s_hi; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < S8_CT; ++ct) acc[ct][HI - 1] = D2T_MFMA(a4[q][ct][s], bv[HI - 1][s], acc[ct][HI - 1]);
+            }
+        };
+        auto kblock = [&](f32x4 (&bv)[NACT], f32x4 (&bvn)[NACT], auto q_c) {
+            constexpr int q = decltype(q_c)::value;
+            mfma(bv, q, 0, 1);
+            D2T_PIN();
+            if (q + 1 < KB_SS) b_fetch(bvn, cur, q + 1, lo_c, hi_c);  // next k-block's G fragments
+            D2T_PIN();
+            mfma(bv, q, 1, 2);
+            D2T_PIN();
+            if (q == 0) store_tile(done, ss - 3);                    // complete since the end of the previous super-step
+            if (q == 1) g_put_all(ring[cur ^ 1]);                    // G(ss+1), requested a super-step ago; that buffer was last read in ss-1
+            if (q == 2) g_load_all(ss + 2);                          // past the map: out of range, zeros
+            D2T_PIN();
+            mfma(bv, q, 2, 4);
+            D2T_PIN();
+#pragma unroll
+            for (int ct = 0; ct < S8_CT; ++ct) a4[q][ct] = s_load(ss + 1, q, ct);   // a whole super-step ahead
+            if (q == KB_SS - 2) {
+                // every wave has issued (and, lgkmcnt(0), received) its last fragments of ring[cur] and written its
+                // part of ring[cur^1]: publish.  The k-block behind the barrier runs from registers.
+                lds_barrier();
+                b_fetch(bv, cur ^ 1, 0, nlo_c, nhi_c);          // bv is free: its last MFMA has been issued
+            }
+            D2T_PIN();
+        };
+        kblock(bvC, bvN, I0{});
+        kblock(bvN, bvC, I1{});
+        kblock(bvC, bvN, I2{});
+        kblock(bvN, bvC, I3{});                                      // ends with the barrier; refills bvN with (ss+1, k-block 0)
+        kblock(bvC, bvN, I4{});
+        // tile ss-2 is complete: keep it for the store in the next super-step, rotate
+#pragma unroll
+        for (int ct = 0; ct < S8_CT; ++ct) {
+            done[ct] = acc[ct][0];
+#pragma unroll
+            for (int a = 0; a + 1 < NACT; ++a) acc[ct][a] = acc[ct][a + 1];
+            acc[ct][NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        D2T_PIN();
+    };
+
+    b_fetch(bvP, 0, 0, I2{}, I5{});
+    // tiles_i >= 5 (host-checked): two leading, tiles_i - 4 full, two trailing super-steps
+    super_step(0, bvP, bvQ, I2{}, I5{}, I1{}, I5{});
+    {
+        super_step(1, bvQ, bvP, I1{}, I5{}, I0{}, I5{});
+        int ss = 2;
+        const int last_full = tiles_i - 3;                           // full super-steps 2 .. tiles_i-3
+        for (; ss + 1 < last_full; ss += 2) {
+            super_step(ss, bvP, bvQ, I0{}, I5{}, I0{}, I5{});
+            super_step(ss + 1, bvQ, bvP, I0{}, I5{}, I0{}, I5{});
+        }
+        if (ss < last_full) {                                        // two full ones left: ss, ss+1 = last_full
+            super_step(ss, bvP, bvQ, I0{}, I5{}, I0{}, I5{});
+            super_step(ss + 1, bvQ, bvP, I0{}, I5{}, I0{}, I4{});
+            super_step(ss + 2, bvP, bvQ, I0{}, I4{}, I0{}, I3{});
+            super_step(ss + 3, bvQ, bvP, I0{}, I3{}, I0{}, I3{});
+        } else {                                                     // one full one left: ss = last_full
+            super_step(ss, bvP, bvQ, I0{}, I5{}, I0{}, I4{});
+            super_step(ss + 1, bvQ, bvP, I0{}, I4{}, I0{}, I3{});
+            super_step(ss + 2, bvP, bvQ, I0{}, I3{}, I0{}, I3{});
+        }
+    }
+    store_tile(done, tiles_i - 3);
+    {
+        const f32x4 t0[S8_CT] = {acc[0][0], acc[1][0]}, t1[S8_CT] = {acc[0][1], acc[1][1]};
+        store_tile(t0, tiles_i - 2);                                 // their remaining super-steps lie below the map
+        store_tile(t1, tiles_i - 1);
+    }
+
+    if (__builtin_expect(__any(badt != 0), 0)) {                     // cold: non-finite inputs only
+        unsigned lo = (unsigned)badt, hi = (unsigned)(badt >> 32);
+#pragma unroll
+        for (int off = 32; off; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
+        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+        for (int ct = 0; ct < S8_CT; ++ct) {
+            if (tiles_i > 64) {
+                strip_repair(role, lane, gb, S, gx, cw + 16 * ct, C, H, W, j0, CELLS, 1, 0, H);
+            } else {
+                for (int u = 0; u < tiles_i; ++u)
+                    if ((m >> u) & 1)
+                        strip_repair(role, lane, gb, S, gx, cw + 16 * ct, C, H, W, j0, CELLS, 1, 4 * u, 4 * u + 4 < H ? 4 * u + 4 : H);
+            }
+        }
+    }
+}
+#undef D2T_PIN
+
+__global__ void __launch_bounds__(S8_THREADS)
+k_corr_bwd_strip8(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
+                  float* __restrict__ g0, float* __restrict__ g1,
+                  int B, int C, int H, int W, int tiles_i, int tiles_j)
+{
+    __shared__ __attribute__((aligned(16))) float ring[2][S8_RING];  // 64 KB
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // both roles of a batch item stay on one XCD: they share gradOut[b]
+    const int tj = bid % tiles_j, role = (bid / tiles_j) & 1, b = bid / (2 * tiles_j);
+    if (role) strip8_body<1>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
+    else strip8_body<0>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
+}
+
+}  // namespace
+
+bool corr_bwd8_supported(int B, int C, int H, int W, int ps, int cs)
+{
+    if (ps != CELLS || cs != 1 || B < 1 || C < 1 || W < WC) return false;
+    const int tiles_i = (H + TP - 1) / TP;
+    if (tiles_i < 5 || tiles_i > 250) return false;                  // super-step numbers are packed into 8 bits
+    // 32-bit byte offsets inside one batch item: feature planes (incl. the c-tile behind C and the rows a
+    // prefetch reaches past the map) and gradOut
+    const bool fits = (C + 64LL) * H * W * 4 + 64LL * W < 0x7ffffff0LL && (1LL * H * W + 8LL * W) * CELLS * 4 < 0x7ffffff0LL;
+    return fits && 2LL * B * ((W + TP - 1) / TP) * ((C + S8_CH - 1) / S8_CH) <= 0x7fffffffLL;
+}
+
+int corr_bwd8_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
+                  int B, int C, int H, int W, hipStream_t st)
+{
+    const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
+    hipLaunchKernelGGL(k_corr_bwd_strip8, dim3(2 * B * tiles_j, (C + S8_CH - 1) / S8_CH), dim3(S8_THREADS), 0, st,
+                       gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    return launch_status();
+}
+
+}}  // namespace d2t::tuned

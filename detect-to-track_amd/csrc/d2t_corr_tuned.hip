@@ -25,16 +25,10 @@
 // block map gives every XCD a contiguous run of segments so that neighbours share L2 lines.
 // The first generation (one p-tile per workgroup, FM1 gathered straight from L2) measured
 // texture-address-bound and is gone; DESIGN.md section 4.2 keeps its numbers.
-#include "d2t_tuned.hpp"
+#include "d2t_corr_common.hpp"
 #include <type_traits>
 
 namespace d2t { namespace tuned {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load, dword aligned
-
-#define D2T_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // In-kernel stamps for the developer harness csrc/lab/fwd_lab.hip (a separate diagnostic build, see
 // the MI355X guide "In-kernel stamps").  The product library is built without D2T_LAB: no stamp
@@ -73,21 +67,6 @@ __device__ unsigned long long* lab_wave_stamps;                     // [workgrou
 #define D2T_WCLK_DECL(...)
 #define D2T_LAB_ONLY(...)
 #endif
-
-constexpr int TP = 4;                      // p-tile edge: 4x4 pixels = MFMA M = 16
-constexpr int DT = 8;                      // d_max the tuned kernels are built for
-constexpr int WR = TP + 2 * DT - 1;        // 19 window rows (and needed columns)
-constexpr int NCG = (WR + 3) / 4;          // 5 column groups per window row
-constexpr int WC = NCG * 4;                // 20 loaded columns
-constexpr int CW = 2 * DT + 1;             // 17
-constexpr int CELLS = CW * CW;             // 289
-
-// Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of logical tiles
-// (bijective for any grid size).  Placement only affects L2 reuse, never results.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
 
 // Where cell (ci, cj) of pixel (i, j) of batch item b lives in the correlation output / gradOut:
 //     b * bs + (i*W + j) * ps + (ci*17 + cj) * cs          (floats)
@@ -135,13 +114,6 @@ static_assert(SG_LDS * 4 <= 160 * 1024, "LDS budget");
 constexpr int SG_AI = SG_KC * 4 * SG_NU / 64;       // 5 DMA wave-instructions move the FM0 pixels of a chunk
 constexpr int SG_MAXDMA = (SG_KC * SG_SLOTS / 64 + SG_AI + SG_WAVES - 1) / SG_WAVES;   // 4: most a wave issues per chunk
 static_assert(SG_KC * 4 * SG_NU % 64 == 0 && SG_MAXDMA <= SG_KC / 4, "DMA plan");
-typedef __attribute__((address_space(3))) void* lds_ptr;
-
-template <int N>
-__device__ __forceinline__ void dma_wait_barrier()
-{
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 
 // The kernel.  Per chunk of 16 channels a wave issues its 2-3 LDS-DMA instructions of chunk ch+2, 4
 // fragment fetches and 4 x NT x 4 MFMAs; the fragments of k-step ks+1 are fetched under the MFMAs of
@@ -430,7 +402,6 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
     for (int e = tid; e < prs * run4; e += SG_THREADS) {
         const int pr = e / run4, q = e - pr * run4;
         const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
                                                ro, off, 0, 0);     // plain write-back stores.  Round 1 used sc1 (write-through: 63 -> 51 us
                                                                    // then); with the ring-of-3 schedule plain stores are 0.9 us faster (A/B, round 2)
@@ -687,7 +658,6 @@ k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, 
     for (int e = tid; e < prs * run4; e += S::THREADS) {
         const int pr = e / run4, q = e - pr * run4;
         const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
                                                ro, off, 0, 16);     // aux 16 = sc1 (write-through)
     }
@@ -786,8 +756,6 @@ int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, i
 constexpr int ST_WAVES = 16;
 constexpr int ST_THREADS = ST_WAVES * 64;
 constexpr int ST_CH = ST_WAVES * 16;                // channels per workgroup pass
-constexpr int NACT = 5;                             // tiles alive during one super-step
-constexpr int KB_SS = 5;                            // k-blocks per super-step
 // (1600 of the 2048 quad slots of a super-step are real: 5 k-blocks x 5 tiles x 64 lanes)
 constexpr int Q_PER_THREAD = 2;                     // every thread produces 2 quads: 2048 slots, 448 unused
 constexpr int RING_SS = Q_PER_THREAD * ST_THREADS * 4;   // 8192 floats = 32 KB per buffer
@@ -918,58 +886,7 @@ __device__ __forceinline__ void strip_vec_put(float* __restrict__ rb, int role, 
     w[0] = v[0]; w[4] = v[1]; w[8] = v[2]; w[12] = v[3];
 }
 
-// ------------------------------------------------------------------------------------
-// Non-finite inputs.  The MFMA form multiplies window slots a tile pixel does not own by an exact
-// 0 weight; an Inf / NaN in the feature map S then turns that product into NaN and poisons the
-// whole accumulator row (channel) of the tile, including pixels whose own window does not contain
-// the bad value -- the reference (pointwise_correlation_cuda.cu:154-171) only ever touches a
-// pixel's own window.  Every poisoned element is itself non-finite, so a wave that stored a
-// non-finite value recomputes ITS region (16 channels x the strip) in the reference's own form at
-// the end of the kernel: gather loops, fused multiply-add chain, ascending order -- the same
-// arithmetic as the type-generic kernel.  Cold code: never runs on finite inputs.  The 16-wave kernel
-// repairs only the 4x4 tiles it stored a non-finite value for (one Inf in a feature map poisons the
-// tiles whose windows contain it, not the strip: a whole-strip repair took 12.6 ms per call when a
-// diverged model fed NaNs).
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ bool nonfinite4(const f32x4& d)
-{
-    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[0]), __builtin_fabsf(d[1])),
-                                    __builtin_fmaxf(__builtin_fabsf(d[2]), __builtin_fabsf(d[3])));
-    return !(m <= 3.4028234663852886e38f) || d[0] != d[0] || d[1] != d[1] || d[2] != d[2] || d[3] != d[3];
-}
-
-__device__ __attribute__((noinline)) void strip_repair(int role, int lane, const float* __restrict__ gb,
-                                                       const float* __restrict__ Sb, float* __restrict__ gxb,
-                                                       int cw, int C, int H, int W, int j0, int ps, int cs, int y0, int y1)
-{
-    const int HW = H * W, nr = y1 - y0;                              // map rows [y0, y1) of the strip
-    for (int e = lane; e < 16 * nr * TP; e += 64) {
-        const int c = cw + e / (nr * TP), rem = e % (nr * TP), y = y0 + rem / TP, x = j0 + rem % TP;
-        if (c >= C || x >= W) continue;
-        const float* sc = Sb + (size_t)c * HW;
-        float a = 0.f;
-        if (role == 0) {                                             // centre (y,x): walk its window of FM1
-            const int lo_i = y - DT > 0 ? y - DT : 0, hi_i = y + DT < H ? y + DT : H;
-            const int lo_j = x - DT > 0 ? x - DT : 0, hi_j = x + DT < W ? x + DT : W;
-            const float* gc = gb + (size_t)(y * W + x) * ps;
-            for (int di = lo_i; di < hi_i; ++di)
-                for (int dj = lo_j; dj < hi_j; ++dj)
-                    a = __builtin_fmaf(gc[(size_t)((di - y + DT) * CW + (dj - x + DT)) * cs], sc[di * W + dj], a);
-        } else {                                                     // displaced (y,x): the centres that reach it
-            const int i_lo = y - DT > 0 ? y - DT : 0, i_hi = y + DT < H - 1 ? y + DT : H - 1;
-            const int j_lo = x - DT > 0 ? x - DT : 0, j_hi = x + DT < W - 1 ? x + DT : W - 1;
-            for (int i = i_lo; i <= i_hi; ++i) {
-                if (!corr_axis_hit(i, y, H, DT, 1)) continue;
-                for (int j = j_lo; j <= j_hi; ++j) {
-                    if (!corr_axis_hit(j, x, W, DT, 1)) continue;
-                    a = __builtin_fmaf(gb[(size_t)(i * W + j) * ps + (size_t)((y - i + DT) * CW + (x - j + DT)) * cs], sc[i * W + j], a);
-                }
-            }
-        }
-        gxb[(size_t)c * HW + y * W + x] = a;
-    }
-}
-
+// (non-finite inputs: strip_repair, d2t_corr_common.hpp)
 template <bool VEC>                                              // VEC: 16-byte gradOut loads (reference layout)
 __global__ void __launch_bounds__(ST_THREADS)
 k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
@@ -1271,16 +1188,21 @@ bool corr_bwd_supported(int B, int C, int H, int W, int d, int s)
 
 size_t corr_bwd_ws_bytes(int, int, int, int, int, int) { return 0; }
 
-// nl problems of one spatial shape.  A level whose 16-wave grid fills at least 100 CUs is launched by
-// itself (k_corr_bwd_strip); the remaining levels share ONE launch of the 4-wave kernel, heaviest first.
+// nl problems of one spatial shape.  A level whose 256-channel grid fills at least 100 CUs is launched by
+// itself (the 8-wave kernel of d2t_corr_bwd8.hip; k_corr_bwd_strip for the channel-major layout, short maps
+// or on request); the remaining levels share ONE launch of the 4-wave kernel, heaviest first.
 int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
-                        float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st)
+                        float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
+                        bool strip16)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     int small[MAXLV], ns = 0;
     for (int l = 0; l < nl; ++l) {
         const long long wide = 2LL * B * tiles_j * ((C[l] + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
-        if (wide >= 100 && lay.cs == 1)
+        if (wide >= 100 && !strip16 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {
+            const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st);
+            if (rc != D2T_OK) return rc;
+        } else if (wide >= 100 && lay.cs == 1)
             hipLaunchKernelGGL(k_corr_bwd_strip<true>, dim3(2 * B * tiles_j, (C[l] + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
                                gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, tiles_i, tiles_j, lay);
         else if (wide >= 100)
@@ -1311,10 +1233,10 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
 }
 
 int corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
-                 int B, int C, int H, int W, int, int, void*, hipStream_t st)
+                 int B, int C, int H, int W, int, int, void*, hipStream_t st, bool strip16)
 {
     const CellLayout lay{CELLS, 1, 1LL * H * W * CELLS};
-    return corr_bwd_levels_f32(1, &gout, &fm0, &fm1, &g0, &g1, &C, B, H, W, lay, st);
+    return corr_bwd_levels_f32(1, &gout, &fm0, &fm1, &g0, &g1, &C, B, H, W, lay, st, strip16);
 }
 
 }}  // namespace d2t::tuned

@@ -22,6 +22,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
  */
 #include <math.h>
+#include <stdlib.h>
 
 /* ---- float instantiation ---- */
 #define T float

@@ -248,6 +248,106 @@ void FN(psroipool_bwd)(const T* gout, const T* rois, T* gin, int R, int nT, int 
                 }
 }
 
+/* ------------------------------------------------------------------------------------
+ * Wide-accumulator yardsticks for the gradients the reference sums with atomicAdd.
+ * The reference's summation order is undefined there (pointwise_correlation_cuda.cu:169,
+ * roipool_cuda.cu:123, ps_roipool_cuda.cu:137), and at thousands of terms per element the
+ * T-precision sum of ANY order carries rounding noise above the 1e-5 contract.  These variants
+ * keep every TERM exactly as the reference forms it (geometry and `g / n` in T, products as one
+ * T-rounded... see each function) but add the terms in double and round once, so a kernel can be
+ * held to 1e-5 of the element's magnitude scale: `mag` (optional, same shape as the gradient)
+ * receives sum |term| in double.
+ * ---------------------------------------------------------------------------------- */
+void FN(roipool_bwd_acc64)(const T* gout, const T* rois, T* gin, double* mag, int R, int C, int H, int W, int k)
+{
+    #pragma omp parallel for schedule(static)
+    for (int c = 0; c < C; ++c) {
+        double* acc = (double*)calloc((size_t)2 * H * W, sizeof(double));
+        double* ab = acc + (size_t)H * W;
+        for (int r = 0; r < R; ++r)
+            for (int i = 0; i < k; ++i)
+                for (int j = 0; j < k; ++j) {
+                    int bb[4];
+                    CAT(roi_bin, SUF)(rois + 4 * r, i, j, H, W, k, bb);
+                    const int n = (bb[1] - bb[0]) * (bb[3] - bb[2]);
+                    const T term = gout[(((long)r * C + c) * k + i) * k + j] / (T)n;   /* roipool_cuda.cu:123, in T */
+                    for (int pI = bb[0]; pI < bb[1]; ++pI)
+                        for (int pJ = bb[2]; pJ < bb[3]; ++pJ) {
+                            acc[(long)pI * W + pJ] += (double)term;
+                            ab[(long)pI * W + pJ] += fabs((double)term);
+                        }
+                }
+        for (long q = 0; q < (long)H * W; ++q) {
+            gin[(long)c * H * W + q] = (T)acc[q];
+            if (mag) mag[(long)c * H * W + q] = ab[q];
+        }
+        free(acc);
+    }
+}
+
+void FN(psroipool_bwd_acc64)(const T* gout, const T* rois, T* gin, double* mag, int R, int nT, int H, int W, int k)
+{
+    const long n_in = (long)nT * k * k * H * W;
+    double* acc = (double*)calloc((size_t)2 * n_in, sizeof(double));
+    double* ab = acc + n_in;
+    for (int r = 0; r < R; ++r)
+        for (int t = 0; t < nT; ++t)
+            for (int i = 0; i < k; ++i)
+                for (int j = 0; j < k; ++j) {
+                    int bb[4];
+                    CAT(psroi_cell, SUF)(rois + 4 * r, i, j, H, W, k, bb);
+                    const int n = (bb[1] - bb[0]) * (bb[3] - bb[2]);
+                    const long ch = (long)(t + 1) * (i * k + j);
+                    T g = gout[(((long)r * nT + t) * k + i) * k + j];
+                    if (n > 0) g /= (T)n;                                               /* ps_roipool_cuda.cu:131, in T */
+                    for (int pI = bb[0]; pI < bb[1]; ++pI)
+                        for (int pJ = bb[2]; pJ < bb[3]; ++pJ) {
+                            acc[(ch * H + pI) * W + pJ] += (double)g;
+                            ab[(ch * H + pI) * W + pJ] += fabs((double)g);
+                        }
+                }
+    for (long q = 0; q < n_in; ++q) { gin[q] = (T)acc[q]; if (mag) mag[q] = ab[q]; }
+    free(acc);
+}
+
+/* correlation: every term g * fm is formed exactly (the product of two T values is exact in double),
+ * summed in double, rounded once.  mag0 / mag1 (optional): sum |g * fm| per element. */
+void FN(corr_bwd_acc64)(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1, double* mag0, double* mag1,
+                        int B, int C, int H, int W, int d, int s)
+{
+    const int cw = 2 * d + 1;
+    const long plane = (long)H * W;
+    #pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b) {
+        for (int c = 0; c < C; ++c) {
+            const long base = ((long)b * C + c) * plane;
+            const T* gb = gout + (long)b * plane * cw * cw;
+            double* acc = (double*)calloc((size_t)4 * plane, sizeof(double));
+            double *a0 = acc, *a1 = acc + plane, *m0 = acc + 2 * plane, *m1 = acc + 3 * plane;
+            for (int i = 0; i < H; ++i)
+                for (int j = 0; j < W; ++j) {
+                    const long ctr = (long)i * W + j;
+                    const int lo_i = i - d > 0 ? i - d : 0, hi_i = i + d < H ? i + d : H;
+                    const int lo_j = j - d > 0 ? j - d : 0, hi_j = j + d < W ? j + d : W;
+                    for (int di = lo_i; di < hi_i; di += s)
+                        for (int dj = lo_j; dj < hi_j; dj += s) {
+                            const long dsp = (long)di * W + dj;
+                            const double g = (double)gb[(((long)i * W + j) * cw + (di - i + d)) * cw + (dj - j + d)];
+                            const double t0 = g * (double)fm1[base + dsp], t1 = g * (double)fm0[base + ctr];
+                            a0[ctr] += t0; m0[ctr] += fabs(t0);
+                            a1[dsp] += t1; m1[dsp] += fabs(t1);
+                        }
+                }
+            for (long q = 0; q < plane; ++q) {
+                g0[base + q] = (T)a0[q]; g1[base + q] = (T)a1[q];
+                if (mag0) mag0[base + q] = m0[q];
+                if (mag1) mag1[base + q] = m1[q];
+            }
+            free(acc);
+        }
+    }
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

@@ -136,3 +136,47 @@ def psroipool_channels(nT, k):
     ch = np.empty((nT, k, k), dtype=np.int32)
     lib().d2t_oracle_psroipool_channels(_p(ch), nT, k)
     return ch
+
+
+# ---- wide-accumulator yardsticks (terms as the reference forms them, summed in double, rounded once):
+# each returns (gradient(s), magnitude(s)) with magnitude = sum |term| per element in float64.  A kernel's
+# f32 gradient is held to  |got - ref| <= 1e-5 * magnitude  (plus one ulp of the result).
+def roipool_bwd_acc64(gout, rois, H, W):
+    gout, rois = _c(gout), _c(rois)
+    R, C, k, _ = gout.shape
+    gin = np.empty((C, H, W), dtype=gout.dtype)
+    mag = np.empty((C, H, W), dtype=np.float64)
+    getattr(lib(), f"d2t_oracle_roipool_bwd_acc64_{_sfx(gout)}")(_p(gout), _p(rois), _p(gin), _p(mag), R, C, H, W, k)
+    return gin, mag
+
+
+def psroipool_bwd_acc64(gout, rois, H, W):
+    gout, rois = _c(gout), _c(rois)
+    R, nT, k, _ = gout.shape
+    gin = np.empty((nT * k * k, H, W), dtype=gout.dtype)
+    mag = np.empty((nT * k * k, H, W), dtype=np.float64)
+    getattr(lib(), f"d2t_oracle_psroipool_bwd_acc64_{_sfx(gout)}")(_p(gout), _p(rois), _p(gin), _p(mag), R, nT, H, W, k)
+    return gin, mag
+
+
+def corr_bwd_acc64(gout, fm0, fm1, d, s):
+    gout, fm0, fm1 = _c(gout), _c(fm0), _c(fm1)
+    B, C, H, W = fm0.shape
+    g0, g1 = np.empty_like(fm0), np.empty_like(fm1)
+    m0, m1 = np.empty(fm0.shape, dtype=np.float64), np.empty(fm0.shape, dtype=np.float64)
+    getattr(lib(), f"d2t_oracle_corr_bwd_acc64_{_sfx(fm0)}")(_p(gout), _p(fm0), _p(fm1), _p(g0), _p(g1), _p(m0), _p(m1),
+                                                              B, C, H, W, d, s)
+    return (g0, g1), (m0, m1)
+
+
+def assert_within_contract(got, ref, mag, rel=1e-5, what="gradient"):
+    """|got - ref| <= rel * sum|terms| + one float32 ulp of the reference, element-wise (NaN patterns must match)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern differs"
+    fin = np.isfinite(ref)
+    tol = rel * np.asarray(mag)[fin] + np.spacing(np.abs(ref[fin]).astype(np.float32)).astype(np.float64)
+    err = np.abs(got[fin] - ref[fin])
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())} elements beyond {rel:g} * sum|terms|; worst err/tol = "
+                           f"{float((err / np.maximum(tol, 1e-300)).max()):.3g}")

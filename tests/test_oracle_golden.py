@@ -85,3 +85,34 @@ def test_oracle_headline_subsample(oracle):
     g0, g1 = oracle.corr_bwd(gout, fm0, fm1, d, 1)
     np.testing.assert_array_equal(g0.ravel()[g["g_idx"]], g["g0_val"])          # thread-owned order
     np.testing.assert_allclose(g1.ravel()[g["g_idx"]], g["g1_val"], rtol=1e-5, atol=1e-5)
+
+
+# ---- the wide-accumulator yardsticks (oracle *_acc64): terms as the reference forms them, summed in double.
+# Pinned here against the reference's own gradients of the fixtures: every f32 fixture gradient (atomicAdd order
+# on the GPU that made it) lies within 1e-5 of sum|terms| of the yardstick, and the yardstick's geometry / terms
+# are the pinned oracle's (same bin functions), so it may stand in for "the reference's value" at shapes where an
+# f32 running sum of any order is noisier than the contract.
+@pytest.mark.parametrize("path", [p for p in golden_files("corr")], ids=golden_ids("corr"))
+def test_acc64_yardstick_correlation(path, oracle):
+    g = load_golden(path)
+    (w0, w1), (m0, m1) = oracle.corr_bwd_acc64(g["gout"], g["fm0"], g["fm1"], int(g["d"]), int(g["s"]))
+    rel = 1e-5 if g["fm0"].dtype == np.float32 else 1e-12
+    oracle.assert_within_contract(g["g0"], w0, m0, rel, "gradFM0")
+    oracle.assert_within_contract(g["g1"], w1, m1, rel, "gradFM1")
+
+
+@pytest.mark.parametrize("path", golden_files("roipool"), ids=golden_ids("roipool"))
+def test_acc64_yardstick_roipool(path, oracle):
+    g = load_golden(path)
+    _, H, W = g["fm"].shape
+    want, mag = oracle.roipool_bwd_acc64(g["gout"], g["rois"], H, W)
+    oracle.assert_within_contract(g["gin"], want, mag, 1e-5 if g["fm"].dtype == np.float32 else 1e-12, "ROIPool gradient")
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("psroipool") if "known_answer" not in p.stem],
+                         ids=[i for i in golden_ids("psroipool") if "known_answer" not in i])
+def test_acc64_yardstick_psroipool(path, oracle):
+    g = load_golden(path)
+    _, H, W = g["fm"].shape
+    want, mag = oracle.psroipool_bwd_acc64(g["gout"], g["rois"], H, W)
+    oracle.assert_within_contract(g["gin"], want, mag, 1e-5 if g["fm"].dtype == np.float32 else 1e-12, "PSROIPool gradient")
