@@ -198,7 +198,10 @@ def main(argv=None):
             total = total + losses
             t5 = mark()
             ev.append((t0, t1, t2, t3, t4, t5))
-        optim.zero_grad(set_to_none=True)
+        if buckets is not None:
+            buckets.zero_grad()                                                    # gradients live in (and stay attached to) the buckets
+        else:
+            optim.zero_grad(set_to_none=True)
         b0e = mark()
         total.backward(coefs)                                                      # :276
         if buckets is not None:

@@ -12,6 +12,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include "../../include/d2t_ops.h"
 
 namespace d2t {
@@ -83,6 +86,39 @@ inline int launch_status() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? D2T_OK : static_cast<int>(e);
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (function, device) pair.  Every launcher that needs more
+// than 64 KB of dynamic LDS sets it for the calling thread's CURRENT device before its first launch there and
+// returns the error if that fails; `done` (one per call site) is a write-once bit per device -- an idempotent
+// cache, safe under concurrent callers (a race sets the attribute twice).
+inline int ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return static_cast<int>(e);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return D2T_OK;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return static_cast<int>(e);
+    if (dev < 64) done.fetch_or(bit, std::memory_order_release);
+    return D2T_OK;
+}
+#define D2T_ENSURE_DYNAMIC_LDS(fn, bytes)                                                                \
+    do {                                                                                                 \
+        static std::atomic<unsigned long long> done_{0};                                                 \
+        const int rc_ = ::d2t::ensure_dynamic_lds(reinterpret_cast<const void*>(fn), (int)(bytes), done_); \
+        if (rc_ != D2T_OK) return rc_;                                                                   \
+    } while (0)
+
+// Developer knobs (environment variables that force one of several measured designs) exist only in harness builds
+// (-DD2T_LAB); the product library reads no environment.
+#ifdef D2T_LAB
+inline int lab_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline const char* lab_env_str(const char* name) { return getenv(name); }
+#else
+inline int lab_env_int(const char*, int dflt) { return dflt; }
+inline const char* lab_env_str(const char*) { return nullptr; }
+#endif
 
 inline bool fits_i32(long long v) { return v >= 0 && v <= 2147483647LL; }
 

@@ -30,15 +30,24 @@
 
 namespace d2t { namespace tuned {
 
+// Per-wave clock reads for the developer harness csrc/lab/bwd8_stamp_lab.hip (a separate diagnostic build, see the
+// MI355X guide "In-kernel stamps"); the product library is built without D2T_LAB: no stamp executes there.
+#ifdef D2T_LAB
+__device__ unsigned long long* lab8_stamps;                         // [workgroup][wave][16]
+#define D2T_WCLK(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define D2T_WRT(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define D2T_LAB_ONLY(...) __VA_ARGS__
+#else
+#define D2T_WCLK(var)
+#define D2T_WRT(var)
+#define D2T_LAB_ONLY(...)
+#endif
+
 namespace {
 
-constexpr int S8_WAVES = 8;
-constexpr int S8_THREADS = S8_WAVES * 64;
-constexpr int S8_CT = 2;                            // c-tiles (16 channels) per wave
-constexpr int S8_CH = S8_WAVES * S8_CT * 16;        // 256 channels per workgroup
+constexpr int S8_CH = 256;                          // channels per workgroup: 16 / CT waves of CT c-tiles (16 channels) each
 constexpr int S8_QUADS = KB_SS * NACT * 64;         // 1600 ring quads per super-step: [k-block][live tile][lane]
-constexpr int S8_NQ = (S8_QUADS + S8_THREADS - 1) / S8_THREADS;   // 4 per thread (the 4th only in wave 0)
-constexpr int S8_RING = S8_NQ * S8_THREADS * 4;     // floats per ring buffer (32 KB)
+constexpr int S8_RING = 2048 * 4;                   // floats per ring buffer (32 KB): 2048 quad slots = 2048 / threads per thread
 constexpr int S8_OOR = 0x7ffffff0;                  // byte offset that every buffer range check rejects
 
 // One ring quad (k-block q of a super-step, live tile a, lane l) as a 16-byte run of gradOut: component c
@@ -51,11 +60,31 @@ constexpr int S8_OOR = 0x7ffffff0;                  // byte offset that every bu
 // the last pixel's row 15 never ends past cell 288), and those components are masked off.
 struct Quad8 { int off, info; };
 
+// Which 4 window slots (one 16-byte piece of a map row) lane group gg of k-block q multiplies: map row 4*ss + xr,
+// column group cg.  ROWKB = false: the 20 groups of a super-step in row-major order, four per k-block (a k-block
+// straddles two rows).  ROWKB = true: k-blocks 0..3 are the first four groups of rows 0..3 (the four pieces of a
+// channel are 64 contiguous bytes: 2 cache lines per channel and load instead of 3-4), k-block 4 collects the
+// fifth group of the four rows.
+template <bool ROWKB>
+__device__ __forceinline__ void kb_slot(int q, int gg, int& xr, int& cg)
+{
+    if (ROWKB) {
+        xr = q < 4 ? q : gg;
+        cg = q < 4 ? gg : 4;
+    } else {
+        const int x = 4 * q + gg;
+        xr = (x * 13) >> 6;                                                // x / 5 (x < 32)
+        cg = x - xr * NCG;
+    }
+}
+
+template <bool ROWKB>
 __device__ __forceinline__ Quad8 quad8_desc(int role, int e, int H, int W, int tiles_i, int j0, int col0)
 {
     const int q = e / (NACT * 64), r = e - q * (NACT * 64);
     const int a = r >> 6, l = r & 63, gg = l >> 4;
-    const int x = 4 * q + gg, xr = (x * 13) >> 6, cg = x - xr * NCG;      // x / 5, x % 5 (x < 32)
+    int xr, cg;
+    kb_slot<ROWKB>(q < KB_SS ? q : 0, gg, xr, cg);
     const int tpi = (l >> 2) & 3, lo2 = l & 3;                             // role 0: lo2 = tile column; role 1: slot column s
     const int ci = role ? 4 * a + tpi - xr : xr - 4 * a - tpi + 2 * DT;    // displaced - centre + d (constant)
     const int tj = j0 + lo2, sj = col0 + 4 * cg + (role ? lo2 : 0);
@@ -104,14 +133,19 @@ typedef std::integral_constant<int, 5> I5;
 
 // The strip walk for one role (compile-time: the two roles differ in the ring write pattern and in which
 // k-block of a tile is structurally zero; a run-time role splits the pinned schedule into many basic blocks).
-template <int role>
+template <int role, int S8_CT, bool ROWKB, int ABL = 0>    // ABL: ablation mask of csrc/lab/bwd8_stamp_lab (timing only)
 __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const float* __restrict__ gout,
                                             const float* __restrict__ fm0, const float* __restrict__ fm1,
                                             float* __restrict__ g0, float* __restrict__ g1,
                                             int b, int tj, int C, int H, int W, int tiles_i)
 {
+    constexpr int S8_WAVES = 16 / S8_CT;
+    constexpr int GT = S8_WAVES * 64, S8_NQ = 2048 / GT;             // threads, ring quads per thread
+    constexpr int DEAD0 = ROWKB ? 3 : KB_SS - 1;                     // the k-block whose slots all lie below a tile's window (role 0)
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    D2T_LAB_ONLY(unsigned long long w_t0, w_t1, w_t2, w_t3, w_r1, w_r2, w_a, w_b, w_sl[3] = {0, 0, 0}, w_bar = 0, w_rot = 0;)
+    D2T_WCLK(w_t0);
     const int j0 = tj * TP, HW = H * W;
     const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
     const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
@@ -129,7 +163,8 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     int sv[KB_SS];
 #pragma unroll
     for (int q = 0; q < KB_SS; ++q) {
-        const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
+        int xr, cg;
+        kb_slot<ROWKB>(q, g, xr, cg);
         sv[q] = ((cw + n) * HW + xr * W + col0 + 4 * cg) * 4;
     }
     const int s_step = 4 * W * 4, ct_step = 16 * HW * 4;
@@ -138,10 +173,13 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
         return __builtin_bit_cast(f32x4, v);
     };
 
-    // ---- G production: this thread's ring quads e = tid + 512 k
+    // ---- G production: ring quads e = tid + GT k, S8_NQ per thread.  (Measured and dropped: waves 0-3 -- which the
+    // hardware favours at the matrix pipe, they reach every barrier a quarter of a super-step early -- producing all
+    // of G in two batches: 72 -> 83 us; alternating s_setprio between the two waves of a SIMD: no change.)
+    const int gtid = tid;
     Quad8 qd[S8_NQ];
 #pragma unroll
-    for (int k = 0; k < S8_NQ; ++k) qd[k] = quad8_desc(role, tid + k * S8_THREADS, H, W, tiles_i, j0, col0);
+    for (int k = 0; k < S8_NQ; ++k) qd[k] = quad8_desc<ROWKB>(role, gtid + k * GT, H, W, tiles_i, j0, col0);
     // (quads 1600..2047 do not exist: their descriptors are empty -- an out-of-range request, zeros into ring
     // slots nobody reads -- so that G production stays branch-free)
     const int g_step = 4 * W * CELLS * 4;                            // gradOut bytes per 4 map rows
@@ -152,7 +190,7 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     };
     auto g_put = [&](float* rb, int k, const f32x4& raw) {
         const f32x4 v = quad8_fix(raw, qd[k].info);
-        const int e = tid + k * S8_THREADS;
+        const int e = gtid + k * GT;
         if (!role) { reinterpret_cast<f32x4*>(rb)[e] = v; return; }
         // role 1: component lo2 = s of the quads of lanes (tpi*4 + c, gg), c = 0..3
         float* w = rb + (((e & ~63) + (lane & 0x3c)) << 2) + (lane & 3);
@@ -176,7 +214,10 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
         if (u < 0 || u >= tiles_i) return;                           // wave-uniform
         const int i = 4 * u + (n >> 2);
         const int base = col_ok && i < H ? x_lane + 4 * u * W * 4 : S8_OOR;
-        badt |= (nonfinite4(d[0]) || nonfinite4(d[1])) && base != S8_OOR ? 1ull << (u & 63) : 0ull;
+        bool bad = false;
+#pragma unroll
+        for (int ct = 0; ct < S8_CT; ++ct) bad = bad || nonfinite4(d[ct]);
+        badt |= bad && base != S8_OOR ? 1ull << (u & 63) : 0ull;
 #pragma unroll
         for (int ct = 0; ct < S8_CT; ++ct)
 #pragma unroll
@@ -195,12 +236,13 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
         for (int a = 0; a < NACT; ++a) acc[ct][a] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- prologue: S pieces of super-step 0, ring[0] <- G(0), registers <- G(1)
+    // ---- prologue: ring[0] <- G(0) (first: load -> LDS -> barrier -> fragment is the longest chain), S pieces of
+    // super-step 0, registers <- G(1)
+    g_load_all(0);
 #pragma unroll
     for (int q = 0; q < KB_SS; ++q)
 #pragma unroll
         for (int ct = 0; ct < S8_CT; ++ct) a4[q][ct] = s_load(0, q, ct);
-    g_load_all(0);
     g_put_all(ring[0]);
     g_load_all(1);
     lds_barrier();
@@ -221,28 +263,18 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         const int cur = ss & 1;
         auto mfma = [&](const f32x4 (&bv)[NACT], int q, int s_lo, int s_hi) {
-            // One k-block of a tile's 25 is structurally zero: for role 0 the last one of its oldest live tile,
-            // for role 1 the first one of its newest; those go behind a wave-uniform branch.
-            const int A0 = (q == KB_SS - 1 && LO == 0) ? 1 : LO;
-            const int A1 = (q == 0 && HI == NACT) ? NACT - 1 : HI;
+            // the last super-step of a map whose height is not a multiple of 4: slot rows >= H carry G = 0
+            if (ROWKB && HI == NACT - 2 && q < 4 && 4 * ss + q >= H) return;     // wave-uniform
+            // One k-block of a tile's 25 is structurally zero: for role 0 the one on the row below its oldest live
+            // tile's window, for role 1 the one on the row above its newest tile's window.
+            const int A0 = (role == 0 && q == DEAD0 && LO == 0) ? 1 : LO;
+            const int A1 = (role == 1 && q == 0 && HI == NACT) ? NACT - 1 : HI;
 #pragma unroll
             for (int s = s_lo; s < s_hi; ++s)
 #pragma unroll
                 for (int a = A0; a < A1; ++a)
 #pragma unroll
                     for (int ct = 0; ct < S8_CT; ++ct) acc[ct][a] = D2T_MFMA(a4[q][ct][s], bv[a][s], acc[ct][a]);
-            if (A0 != LO && role) {
-#pragma unroll
-                for (int s = s_lo; s < s_hi; ++s)
-#pragma unroll
-                    for (int ct = 0; ct < S8_CT; ++ct) acc[ct][LO] = D2T_MFMA(a4[q][ct][s], bv[LO][s], acc[ct][LO]);
-            }
-            if (A1 != HI && !role) {
-#pragma unroll
-                for (int s = s_lo; s < s_hi; ++s)
-#pragma unroll
-                    for (int ct = 0; ct < S8_CT; ++ct) acc[ct][HI - 1] = D2T_MFMA(a4[q][ct][s], bv[HI - 1][s], acc[ct][HI - 1]);
-            }
         };
         auto kblock = [&](f32x4 (&bv)[NACT], f32x4 (&bvn)[NACT], auto q_c) {
             constexpr int q = decltype(q_c)::value;
@@ -252,18 +284,27 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
             D2T_PIN();
             mfma(bv, q, 1, 2);
             D2T_PIN();
-            if (q == 0) store_tile(done, ss - 3);                    // complete since the end of the previous super-step
-            if (q == 1) g_put_all(ring[cur ^ 1]);                    // G(ss+1), requested a super-step ago; that buffer was last read in ss-1
-            if (q == 2) g_load_all(ss + 2);                          // past the map: out of range, zeros
+            if (q <= 2) D2T_WCLK(w_a);
+            if (q == 0) {                            // complete since the end of the previous super-step
+                if (!(ABL & 2)) store_tile(done, ss - 3);
+                else asm volatile("" ::"v"(done[0]), "v"(done[S8_CT - 1]));
+            }
+            if (q == 1 && !(ABL & 8)) g_put_all(ring[cur ^ 1]);      // G(ss+1), requested a super-step ago; that buffer was last read in ss-1
+            if (q == 2 && !(ABL & 4)) g_load_all(ss + 2);            // past the map: out of range, zeros
+            if (q <= 2) { D2T_WCLK(w_b); D2T_LAB_ONLY(w_sl[q <= 2 ? q : 0] += w_b - w_a;) }
             D2T_PIN();
             mfma(bv, q, 2, 4);
             D2T_PIN();
 #pragma unroll
-            for (int ct = 0; ct < S8_CT; ++ct) a4[q][ct] = s_load(ss + 1, q, ct);   // a whole super-step ahead
+            for (int ct = 0; ct < S8_CT; ++ct)
+                if (!(ABL & 1)) a4[q][ct] = s_load(ss + 1, q, ct);   // a whole super-step ahead
             if (q == KB_SS - 2) {
                 // every wave has issued (and, lgkmcnt(0), received) its last fragments of ring[cur] and written its
                 // part of ring[cur^1]: publish.  The k-block behind the barrier runs from registers.
+                D2T_WCLK(w_a);
                 lds_barrier();
+                D2T_WCLK(w_b);
+                D2T_LAB_ONLY(w_bar += w_b - w_a;)
                 b_fetch(bv, cur ^ 1, 0, nlo_c, nhi_c);          // bv is free: its last MFMA has been issued
             }
             D2T_PIN();
@@ -274,6 +315,7 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
         kblock(bvN, bvC, I3{});                                      // ends with the barrier; refills bvN with (ss+1, k-block 0)
         kblock(bvC, bvN, I4{});
         // tile ss-2 is complete: keep it for the store in the next super-step, rotate
+        D2T_WCLK(w_a);
 #pragma unroll
         for (int ct = 0; ct < S8_CT; ++ct) {
             done[ct] = acc[ct][0];
@@ -282,9 +324,12 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
             acc[ct][NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         D2T_PIN();
+        D2T_WCLK(w_b);
+        D2T_LAB_ONLY(w_rot += w_b - w_a;)
     };
 
     b_fetch(bvP, 0, 0, I2{}, I5{});
+    D2T_WCLK(w_t1); D2T_WRT(w_r1);
     // tiles_i >= 5 (host-checked): two leading, tiles_i - 4 full, two trailing super-steps
     super_step(0, bvP, bvQ, I2{}, I5{}, I1{}, I5{});
     {
@@ -306,13 +351,25 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
             super_step(ss + 2, bvP, bvQ, I0{}, I3{}, I0{}, I3{});
         }
     }
+    D2T_WCLK(w_t2); D2T_WRT(w_r2);
     store_tile(done, tiles_i - 3);
     {
-        const f32x4 t0[S8_CT] = {acc[0][0], acc[1][0]}, t1[S8_CT] = {acc[0][1], acc[1][1]};
+        f32x4 t0[S8_CT], t1[S8_CT];
+#pragma unroll
+        for (int ct = 0; ct < S8_CT; ++ct) { t0[ct] = acc[ct][0]; t1[ct] = acc[ct][1]; }
         store_tile(t0, tiles_i - 2);                                 // their remaining super-steps lie below the map
         store_tile(t1, tiles_i - 1);
     }
 
+#ifdef D2T_LAB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    D2T_WCLK(w_t3);
+    if (lane == 0) {
+        unsigned long long* o = lab8_stamps + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * S8_WAVES + wave) * 16;
+        o[0] = w_t0; o[1] = w_t1; o[2] = w_t2; o[3] = w_t3; o[4] = w_r1; o[5] = w_r2; o[6] = w_sl[0]; o[7] = w_sl[1]; o[8] = w_sl[2];
+        o[9] = w_bar; o[10] = w_rot;
+    }
+#endif
     if (__builtin_expect(__any(badt != 0), 0)) {                     // cold: non-finite inputs only
         unsigned lo = (unsigned)badt, hi = (unsigned)(badt >> 32);
 #pragma unroll
@@ -331,7 +388,8 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
 }
 #undef D2T_PIN
 
-__global__ void __launch_bounds__(S8_THREADS)
+template <int CT, bool ROWKB, int ABL = 0>
+__global__ void __launch_bounds__(1024 / CT)
 k_corr_bwd_strip8(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
                   float* __restrict__ g0, float* __restrict__ g1,
                   int B, int C, int H, int W, int tiles_i, int tiles_j)
@@ -339,8 +397,8 @@ k_corr_bwd_strip8(const float* __restrict__ gout, const float* __restrict__ fm0,
     __shared__ __attribute__((aligned(16))) float ring[2][S8_RING];  // 64 KB
     const int bid = xcd_remap(blockIdx.x, gridDim.x);                // both roles of a batch item stay on one XCD: they share gradOut[b]
     const int tj = bid % tiles_j, role = (bid / tiles_j) & 1, b = bid / (2 * tiles_j);
-    if (role) strip8_body<1>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
-    else strip8_body<0>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
+    if (role) strip8_body<1, CT, ROWKB, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
+    else strip8_body<0, CT, ROWKB, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
 }
 
 }  // namespace
@@ -356,12 +414,25 @@ bool corr_bwd8_supported(int B, int C, int H, int W, int ps, int cs)
     return fits && 2LL * B * ((W + TP - 1) / TP) * ((C + S8_CH - 1) / S8_CH) <= 0x7fffffffLL;
 }
 
-int corr_bwd8_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
-                  int B, int C, int H, int W, hipStream_t st)
+#ifdef D2T_LAB
+template <int ABL>
+void lab8_launch(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1, int B, int C, int H, int W)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
-    hipLaunchKernelGGL(k_corr_bwd_strip8, dim3(2 * B * tiles_j, (C + S8_CH - 1) / S8_CH), dim3(S8_THREADS), 0, st,
+    hipLaunchKernelGGL((k_corr_bwd_strip8<2, true, ABL>), dim3(2 * B * tiles_j, (C + S8_CH - 1) / S8_CH), dim3(512), 0, 0,
                        gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+}
+#endif
+
+int corr_bwd8_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
+                  int B, int C, int H, int W, hipStream_t st, int variant)
+{
+    const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
+    const dim3 grid(2 * B * tiles_j, (C + S8_CH - 1) / S8_CH);
+if (variant == 1)                                                // the row-major k-block enumeration (A/B measurements)
+        hipLaunchKernelGGL((k_corr_bwd_strip8<2, false>), grid, dim3(512), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    else
+        hipLaunchKernelGGL((k_corr_bwd_strip8<2, true>), grid, dim3(512), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
     return launch_status();
 }
 

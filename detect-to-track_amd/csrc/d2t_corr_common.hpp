@@ -106,6 +106,6 @@ static __device__ __attribute__((noinline)) void strip_repair(int role, int lane
 // d2t_corr_bwd8.hip
 bool corr_bwd8_supported(int B, int C, int H, int W, int ps, int cs);
 int  corr_bwd8_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
-                   int B, int C, int H, int W, hipStream_t st);
+                   int B, int C, int H, int W, hipStream_t st, int variant = 0);
 
 }}  // namespace d2t::tuned

@@ -1193,14 +1193,14 @@ size_t corr_bwd_ws_bytes(int, int, int, int, int, int) { return 0; }
 // or on request); the remaining levels share ONE launch of the 4-wave kernel, heaviest first.
 int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
                         float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
-                        bool strip16)
+                        int bwd_variant)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     int small[MAXLV], ns = 0;
     for (int l = 0; l < nl; ++l) {
         const long long wide = 2LL * B * tiles_j * ((C[l] + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
-        if (wide >= 100 && !strip16 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {
-            const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st);
+        if (wide >= 100 && bwd_variant != 1 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {
+            const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st, bwd_variant == 2);
             if (rc != D2T_OK) return rc;
         } else if (wide >= 100 && lay.cs == 1)
             hipLaunchKernelGGL(k_corr_bwd_strip<true>, dim3(2 * B * tiles_j, (C[l] + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
@@ -1233,10 +1233,10 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
 }
 
 int corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
-                 int B, int C, int H, int W, int, int, void*, hipStream_t st, bool strip16)
+                 int B, int C, int H, int W, int, int, void*, hipStream_t st, int bwd_variant)
 {
     const CellLayout lay{CELLS, 1, 1LL * H * W * CELLS};
-    return corr_bwd_levels_f32(1, &gout, &fm0, &fm1, &g0, &g1, &C, B, H, W, lay, st, strip16);
+    return corr_bwd_levels_f32(1, &gout, &fm0, &fm1, &g0, &g1, &C, B, H, W, lay, st, bwd_variant);
 }
 
 }}  // namespace d2t::tuned

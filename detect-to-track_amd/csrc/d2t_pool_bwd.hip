@@ -481,15 +481,13 @@ static int roipool_bwd_mfma_f32(const float* gout, const float* rois, float* gin
     if (rc != D2T_OK) return rc;
     const int xt = (W + 15) / 16;
     // (c-tiles per task, waves per task): D2T_ROI_CFG=1..4 -> (1,4) | (2,4) | (4,4) | (2,2); a lab knob, read once
-    static const int cfg = [] { const char* e = getenv("D2T_ROI_CFG"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }();
+    static const int cfg = [] { const int v = lab_env_int("D2T_ROI_CFG", 2); return v >= 1 && v <= 4 ? v : 2; }();   // -DD2T_LAB only
     const int nct = cfg == 1 ? 1 : cfg == 3 ? 4 : 2;
     const int ncb = (C + 16 * nct - 1) / (16 * nct), ntasks = H * ncb;
 #define D2T_LAUNCH_GEMM(XTV, NCTV, NWV)                                                                        \
     {                                                                                                          \
         const size_t lds = 4 * RG_CH * sizeof(RmSlot) + (size_t)NWV * NCTV * XTV * 64 * sizeof(f32x4);         \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_roipool_bwd_gemm<XTV, NCTV, NWV>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        (void)attr;                                                                                            \
+        D2T_ENSURE_DYNAMIC_LDS((k_roipool_bwd_gemm<XTV, NCTV, NWV>), 160 * 1024);                              \
         int per_cu = (int)((size_t)(160 * 1024) / (lds + 64));                                                 \
         const int by_waves = 16 / NWV;                                                                         \
         per_cu = per_cu > by_waves ? by_waves : per_cu;                                                        \
@@ -514,7 +512,7 @@ static bool roipool_bwd_pixel_supported(int R, int C, int H, int W, int k)
 // D2T_ROI_BWD=pixel|mfma forces one of the two designs (a lab knob for A/B measurements, read once)
 static bool roipool_bwd_use_mfma(int R, int C, int H, int W, int k)
 {
-    static const int forced = [] { const char* e = getenv("D2T_ROI_BWD"); return !e ? 0 : !strcmp(e, "pixel") ? 1 : !strcmp(e, "mfma") ? 2 : 0; }();
+    static const int forced = [] { const char* e = lab_env_str("D2T_ROI_BWD"); return !e ? 0 : !strcmp(e, "pixel") ? 1 : !strcmp(e, "mfma") ? 2 : 0; }();   // -DD2T_LAB only
     const bool m = roipool_bwd_mfma_supported(R, C, H, W, k), p = roipool_bwd_pixel_supported(R, C, H, W, k);
     if (!m || !p) return m;
     return forced != 1;
@@ -1037,9 +1035,7 @@ static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* g
 #define D2T_LAUNCH_PG(XTV, NCTV, NWV)                                                                          \
     {                                                                                                          \
         const size_t lds = PG_CH * sizeof(RmSlot) + (size_t)NWV * NCTV * XTV * 64 * sizeof(f32x4);             \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ps_bwd_gemm<XTV, NCTV, NWV>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        (void)attr;                                                                                            \
+        D2T_ENSURE_DYNAMIC_LDS((k_ps_bwd_gemm<XTV, NCTV, NWV>), 160 * 1024);                                   \
         hipLaunchKernelGGL((k_ps_bwd_gemm<XTV, NCTV, NWV>), dim3(ntasks), dim3(NWV * 64), lds, st, vt, lists, counts, part, R, nT, nTp, H, W); \
     }
 #define D2T_LAUNCH_PG_X(NCTV, NWV) { if (xt <= 4) D2T_LAUNCH_PG(4, NCTV, NWV) else if (xt <= 5) D2T_LAUNCH_PG(5, NCTV, NWV) else D2T_LAUNCH_PG(8, NCTV, NWV) }
@@ -1067,7 +1063,7 @@ constexpr int PS_SORTED_MIN_TARGETS = 12;
 static int ps_bwd_forced()
 {
     static const int v = [] {
-        const char* e = getenv("D2T_PS_BWD");
+        const char* e = lab_env_str("D2T_PS_BWD");                       // -DD2T_LAB only
         if (!e) return 0;
         return !strcmp(e, "planes") ? 1 : !strcmp(e, "sorted") ? 2 : !strcmp(e, "gemm") ? 3 : 0;
     }();

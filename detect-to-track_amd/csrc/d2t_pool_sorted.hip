@@ -350,11 +350,8 @@ int psroipool_bwd_sorted_f32(const float* gout, const float* rois, float* gin, i
     const int cap = (4 * R + 7) & ~7;                                // 16-byte multiple of u16 entries per list
     int rc = ps_cells_T(rois, cellsT, R, H, W, st);
     if (rc != D2T_OK) return rc;
-    static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ps_corner_lists),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_psroipool_bwd_sorted),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    (void)a1; (void)a2;
+    D2T_ENSURE_DYNAMIC_LDS(k_ps_corner_lists, LDS_MAX);
+    D2T_ENSURE_DYNAMIC_LDS(k_psroipool_bwd_sorted, LDS_MAX);
     hipLaunchKernelGGL(k_ps_corner_lists, dim3(KK), dim3(CL_THREADS), corner_list_lds(cap), st, cellsT, lists, segs, nn, R, L.LDW, cap);
     rc = launch_status();
     if (rc != D2T_OK) return rc;

@@ -297,7 +297,7 @@ static int sat_cg(int C, int H, int W)
     // Two channels per workgroup: 45 KB of LDS, so two workgroups share a CU and one's table build
     // overlaps the other's look-ups (config 3: 37.5 us; 4 channels = one workgroup per CU: 40.7; 1: 47.1).
     // D2T_SAT_CG=1|2|4 overrides (lab knob for that measurement, read once).
-    static const int top = [] { const char* e = getenv("D2T_SAT_CG"); const int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();
+    static const int top = [] { const int v = lab_env_int("D2T_SAT_CG", 2); return v == 1 || v == 4 ? v : 2; }();   // -DD2T_LAB only
     for (int cg = top; cg >= 1; cg >>= 1)
         if (sat_layout(cg, H, W).bytes <= (size_t)LDS_MAX && (cg == 1 || C >= 2 * cg)) return cg;
     return sat_layout(1, H, W).bytes <= (size_t)LDS_MAX ? 1 : 0;
@@ -324,17 +324,13 @@ int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C
     const dim3 grid(gx, (R + per - 1) / per);
 #define D2T_LAUNCH_SAT(CGV)                                                                              \
     {                                                                                                    \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_roipool_fwd_sat<CGV>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX); \
-        (void)attr;                                                                                      \
+        D2T_ENSURE_DYNAMIC_LDS(k_roipool_fwd_sat<CGV>, LDS_MAX);                                        \
         hipLaunchKernelGGL(k_roipool_fwd_sat<CGV>, grid, dim3(RF_THREADS), L.bytes, st, fm, rois, out, R, C, H, W, \
                            L.LD, L.plane, per);                                                          \
     }
-    static const int inter = [] { const char* e = getenv("D2T_SAT_INTERLEAVED"); return e ? atoi(e) : 1; }();   // lab knob
+    static const int inter = lab_env_int("D2T_SAT_INTERLEAVED", 1);   // -DD2T_LAB only
     if (CG == 2 && inter) {
-        static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_roipool_fwd_sat2),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        (void)attr2;
+        D2T_ENSURE_DYNAMIC_LDS(k_roipool_fwd_sat2, LDS_MAX);
         hipLaunchKernelGGL(k_roipool_fwd_sat2, grid, dim3(S2_THREADS), L.bytes, st, fm, rois, out, R, C, H, W, L.LD, L.plane, per);
         return launch_status();
     }
@@ -438,9 +434,7 @@ int psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int
     int rc = ps_cells_T(rois, cellsT, R, H, W, st);
     if (rc != D2T_OK) return rc;
     const size_t lds = (((size_t)H * W * 4 + 15) & ~(size_t)15) + 256;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_psroipool_fwd_chan),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    (void)attr;
+    D2T_ENSURE_DYNAMIC_LDS(k_psroipool_fwd_chan, LDS_MAX);
     hipLaunchKernelGGL(k_psroipool_fwd_chan, dim3(nT * KK + nT - 1, (R + PF_RC - 1) / PF_RC), dim3(256), lds, st,
                        fm, cellsT, tmpT, R, nT, H, W);
     rc = launch_status();

@@ -21,12 +21,12 @@ int    corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* 
                            int B, int H, int W, CellLayout lay, hipStream_t st);
 int    corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
                            float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
-                           bool strip16 = false);
+                           int bwd_variant = 0);
 
 bool   corr_bwd_supported(int B, int C, int H, int W, int d, int s);
 size_t corr_bwd_ws_bytes(int B, int C, int H, int W, int d, int s);
 int    corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
-                    int B, int C, int H, int W, int d, int s, void* ws, hipStream_t st, bool strip16 = false);
+                    int B, int C, int H, int W, int d, int s, void* ws, hipStream_t st, int bwd_variant = 0);
 
 bool   roipool_fwd_supported(int R, int C, int H, int W, int k);
 size_t roipool_fwd_ws_bytes(int R, int C, int H, int W, int k);

@@ -8,18 +8,30 @@ parameter gradients -- and on MI355X that is RCCL over xGMI (``torch.distributed
 * gradients are packed into a few LARGE flat buckets (default 64 MB: xGMI is point-to-point, 7 links x
   ~153 GB/s per GPU, so a ring all-reduce is bound per link and pays its latency per call -- the model's
   37 M trainable parameters are 150 MB, i.e. three calls, not hundreds);
-* buckets are filled in the order gradients become ready (reverse registration order) and a bucket's
-  all-reduce is launched ASYNCHRONOUSLY the moment its last gradient arrives, from autograd's
-  post-accumulate hooks, so that it runs under the rest of the backward pass (the backbone's early
-  stages finish last and are the cheapest to wait for);
-* ``wait()`` -- called once between ``backward()`` and ``optimizer.step()`` -- completes the handles,
-  launches buckets that stayed incomplete (parameters that got no gradient this step count as
-  zeros, on every rank alike), divides by the world size and hands the averages back to ``p.grad``.
+* ``p.grad`` IS a view of its bucket (gradient-as-bucket-view): autograd accumulates straight into the
+  flat buffer and the averaged values are read from it by the optimizer -- no copy in, no copy out
+  (2 x 150 MB per step otherwise);
+* buckets are filled in the order gradients become ready (reverse registration order) and all-reduced
+  ASYNCHRONOUSLY from autograd's post-accumulate hooks, under the rest of the backward pass (the
+  backbone's early stages finish last and are the cheapest to wait for) -- always in BUCKET ORDER: a bucket
+  whose last gradient has arrived waits for its predecessors, so that every rank issues the same sequence
+  of collectives even when a parameter gets a gradient on one rank and none on another;
+* ``wait()`` -- called once between the last ``backward()`` and ``optimizer.step()`` -- launches the
+  buckets that stayed incomplete (a parameter without a gradient this step contributes the zeros
+  ``zero_grad()`` left in its view), completes the handles and divides by the world size;
+* gradient accumulation: run every micro-batch but the last under ``with buckets.no_sync():`` -- the hooks
+  then only let autograd accumulate; the last ``backward()`` reduces the sums.
 
-Nothing here touches the data path of the ops; there is no CPU fallback to speak of either: on CPU
-tensors with the gloo backend the same code runs unchanged, which is how tests/test_data_parallel_gloo.py
-covers it (world_size 2).  It has NOT run on multi-GPU hardware yet.
+Use ``buckets.zero_grad()`` instead of ``optimizer.zero_grad()`` (which, with ``set_to_none=True``, would
+detach the gradients from the buckets; a gradient found detached is copied back and re-attached, so that
+is a slow path, not an error).  Like DistributedDataParallel with ``find_unused_parameters``, a parameter
+that got no gradient on any rank ends the step with a zero gradient rather than ``None``.
+
+Nothing here touches the data path of the ops; on CPU tensors with the gloo backend the same code runs
+unchanged, which is how tests/test_data_parallel_gloo.py covers it (world_size 2).  It has NOT run on
+multi-GPU hardware yet.
 """
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -28,7 +40,7 @@ from torch import Tensor
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "offsets", "pending", "ready", "handle")
+    __slots__ = ("flat", "params", "offsets", "views", "pending", "ready", "seen", "handle")
 
     def __init__(self, params: List[Tensor], dtype: torch.dtype, device: torch.device) -> None:
         self.params = params
@@ -37,8 +49,10 @@ class _Bucket:
             self.offsets.append(n)
             n += p.numel()
         self.flat = torch.zeros(n, dtype=dtype, device=device)
+        self.views = [self.flat[o: o + p.numel()].view_as(p) for o, p in zip(self.offsets, params)]
         self.pending = len(params)
         self.ready = [False] * len(params)
+        self.seen = [False] * len(params)                # got a gradient in this step (any micro-batch)
         self.handle = None
 
 
@@ -72,44 +86,77 @@ class GradientBuckets:
         self.buckets.append(_Bucket(cur, plist[0].dtype, plist[0].device))
         self._where = {}
         self._hooks = []
-        for b in self.buckets:
+        self._sync = True
+        self._next = 0                                   # first bucket whose all-reduce has not been launched this step
+        for i, b in enumerate(self.buckets):
             for k, p in enumerate(b.params):
-                self._where[p] = (b, k)
+                self._where[p] = (i, k)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.zero_grad()
 
-    def _launch(self, b: _Bucket) -> None:
-        b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    # ------------------------------------------------------------------ gradients live in the buckets
+    def zero_grad(self) -> None:
+        """Zero every gradient and (re-)attach ``p.grad`` to its bucket view."""
+        for b in self.buckets:
+            b.flat.zero_()
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Micro-batches whose gradients are only accumulated (every ``backward()`` but the step's last)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    # ------------------------------------------------------------------ collectives, in bucket order
+    def _launch_ready(self, force: bool = False) -> None:
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b.pending and not force:
+                return
+            if self.world > 1:
+                b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._next += 1
 
     def _on_grad(self, p: Tensor) -> None:
-        b, k = self._where[p]
-        if b.ready[k]:                                   # a second accumulation into the same parameter (gradient
-            return                                       # accumulation over micro-batches): wait() picks up the final value
-        n = p.numel()
-        b.flat[b.offsets[k]: b.offsets[k] + n].copy_(p.grad.reshape(-1))
+        i, k = self._where[p]
+        b = self.buckets[i]
+        if p.grad is not b.views[k] and p.grad.data_ptr() != b.views[k].data_ptr():
+            # detached by optimizer.zero_grad(set_to_none=True) or by the caller: autograd has just created this
+            # tensor with the step's first gradient of p; it moves into the bucket (whose content is last step's)
+            # and later micro-batches accumulate there
+            b.views[k].copy_(p.grad)
+            p.grad = b.views[k]
+        b.seen[k] = True
+        if not self._sync or b.ready[k]:
+            return
         b.ready[k] = True
         b.pending -= 1
-        if b.pending == 0 and self.world > 1:
-            self._launch(b)
+        if b.pending == 0:
+            self._launch_ready()
 
     def wait(self) -> None:
-        """Finish the step's all-reduces and leave the averaged gradients in ``p.grad``."""
+        """Finish the step's all-reduces; afterwards every ``p.grad`` holds the average over the ranks."""
+        for b in self.buckets[self._next:]:              # not launched: some parameter got no gradient on this rank --
+            for k, p in enumerate(b.params):             # it contributes zeros (left by zero_grad(), or written here if
+                if not b.seen[k] and p.grad is None:     # the caller detached the gradient with set_to_none)
+                    b.views[k].zero_()
+        self._launch_ready(force=True)
         for b in self.buckets:
-            if self.world > 1:
-                if b.handle is None:                     # some parameter got no gradient: zeros, same on every rank
-                    for k, p in enumerate(b.params):
-                        if not b.ready[k]:
-                            b.flat[b.offsets[k]: b.offsets[k] + p.numel()].zero_()
-                    self._launch(b)
+            if b.handle is not None:
                 b.handle.wait()
                 b.flat.div_(self.world)
-                for k, p in enumerate(b.params):
-                    if p.grad is not None:
-                        p.grad.copy_(b.flat[b.offsets[k]: b.offsets[k] + p.numel()].view_as(p.grad))
-                    elif b.ready[k] is False and bool(b.flat[b.offsets[k]: b.offsets[k] + p.numel()].any()):
-                        p.grad = b.flat[b.offsets[k]: b.offsets[k] + p.numel()].view_as(p).clone()
+            for p, v in zip(b.params, b.views):          # a parameter unused on THIS rank may have a gradient from others
+                if p.grad is None:
+                    p.grad = v
             b.handle = None
             b.pending = len(b.params)
             b.ready = [False] * len(b.params)
+            b.seen = [False] * len(b.params)
+        self._next = 0
 
     def remove(self) -> None:
         for h in self._hooks:

@@ -28,8 +28,10 @@
  *     d2t_*_workspace_bytes(...) bytes (may be NULL when that returns 0).
  *   - Return value: 0 on success; a negative D2T_E* code for argument errors; a
  *     positive value is a hipError_t from the launch.  The library keeps no pointers
- *     after return and has no mutable global state (re-entrant: autograd calls
- *     backward from another thread).
+ *     after return and is re-entrant (autograd calls backward from another thread).  Its only
+ *     process state is an idempotent write-once flag per (kernel, device) recording that the
+ *     kernel's dynamic-LDS limit has been raised on that device; a failure to raise it is
+ *     returned as the hipError_t.  The library reads no environment variable.
  *   - All extents are int32, like the reference's index arithmetic
  *     (pointwise_correlation_cuda.cu:19-50); shapes whose element count would exceed
  *     2^31-1 are rejected with D2T_ETOOBIG.

@@ -54,13 +54,38 @@ def _worker(rank, world, port, q):
                 parts = [torch.empty_like(g) for _ in range(world)]
                 dist.all_gather(parts, g)
                 torch.testing.assert_close(p.grad, torch.stack(parts).mean(0), rtol=1e-6, atol=1e-7)
-            assert extra.grad is None                              # zeros everywhere: stays without a gradient
+            assert extra.grad is not None and not extra.grad.any()  # no gradient on any rank: zeros (as DDP's unused parameters)
             opt.step()
         # after identical averaged updates the replicas still agree bit for bit
         for p in m.parameters():
             parts = [torch.empty_like(p.data) for _ in range(world)]
             dist.all_gather(parts, p.data)
             assert torch.equal(parts[0], parts[1])
+        # gradient accumulation: two micro-batches, the first under no_sync(); the reduced value is the mean over
+        # ranks of the SUM of both micro-batches' local gradients (the second one used to be dropped)
+        gb.zero_grad()
+        torch.manual_seed(900 + rank)
+        xa, ya, xb, yb = torch.randn(6, 12), torch.randn(6, 5), torch.randn(6, 12), torch.randn(6, 5)
+        la = [g.clone() for g in torch.autograd.grad((m(xa) - ya).square().mean(), list(m.parameters()))]
+        lb = [g.clone() for g in torch.autograd.grad((m(xb) - yb).square().mean(), list(m.parameters()))]
+        with gb.no_sync():
+            (m(xa) - ya).square().mean().backward()
+        (m(xb) - yb).square().mean().backward()
+        gb.wait()
+        for p, ga, gbb in zip(m.parameters(), la, lb):
+            parts = [torch.empty_like(ga) for _ in range(world)]
+            dist.all_gather(parts, ga + gbb)
+            torch.testing.assert_close(p.grad, torch.stack(parts).mean(0), rtol=1e-5, atol=1e-7)
+            assert p.grad.data_ptr() == gb.buckets[gb._where[p][0]].views[gb._where[p][1]].data_ptr()   # still the bucket view
+        # a parameter used on rank 0 only (rank-asymmetric graph): both ranks must still issue the same collectives
+        # in the same order (completion-order launches would hang or cross-match here)
+        gb.zero_grad()
+        torch.manual_seed(77 + rank)
+        x = torch.randn(6, 12)
+        loss = m(x).square().mean() + (extra.sum() * 3.0 if rank == 0 else 0.0)
+        loss.backward()
+        gb.wait()
+        torch.testing.assert_close(extra.grad, torch.full((7,), 3.0 / world))      # mean of (3, 0)
         gb.remove()
         dist.barrier()
         q.put((rank, "ok"))

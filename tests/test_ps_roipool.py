@@ -92,6 +92,9 @@ CASES = [  # (R, nT, H, W, k)
     (64, 31, 38, 75, 7), (5, 2, 11, 10, 7), (1, 1, 3, 3, 1), (130, 4, 20, 20, 5),
     (1200, 13, 38, 75, 7), (1000, 16, 21, 30, 7),        # backward as a GEMM (auto dispatch from 12 targets up)
     (260, 32, 9, 100, 7), (1100, 9, 38, 63, 7), (40, 33, 12, 20, 7),   # 32 targets x 7 column tiles; 8..11 targets at R >= 1000; 33 targets: not the GEMM
+    # the sorted-corner-list backward (d2t_pool_sorted.hip) under DEFAULT dispatch: the GEMM form does not apply (more than
+    # 32 targets / maps wider than 128 columns) and there are >= 12 targets with R * nT >= 14000
+    (500, 33, 38, 63, 7), (800, 20, 20, 140, 7),
 ]
 
 
@@ -115,7 +118,8 @@ def test_matches_oracle(case, dtype, impl, oracle):
     np.testing.assert_array_equal(_n(_ext.ps_roipool_channels(nT, k, DEV)), oracle.psroipool_channels(nT, k))
 
 
-@pytest.mark.parametrize("case", [(300, 21, 38, 63, 7), (3000, 31, 38, 75, 7), (3000, 4, 38, 75, 7), (11, 3, 38, 63, 7)],
+@pytest.mark.parametrize("case", [(300, 21, 38, 63, 7), (3000, 31, 38, 75, 7), (3000, 4, 38, 75, 7), (11, 3, 38, 63, 7),
+                                  (500, 33, 38, 63, 7), (800, 20, 20, 140, 7)],     # the last two: sorted corner lists
                          ids=str)
 def test_matches_live_reference(case, ref_modules, oracle):
     from detect_to_track.models import _ext

@@ -100,6 +100,7 @@ def _ps_cases():
     for _ in range(8):                                                       # 12..32 targets: the backward's GEMM form
         cases.append((int(rng.integers(1, 400)), int(rng.integers(12, 33)), int(rng.integers(1, 50)), int(rng.integers(1, 129))))
     cases += [(1200, 9, 20, 30), (70, 33, 11, 40), (33, 20, 10, 140)]        # 8..11 targets at R >= 1000; beyond 32 targets / 128 columns: other designs
+    cases += [(450, 33, 30, 41), (720, 20, 16, 140), (1500, 40, 12, 20)]     # ... with R * nT >= 14000: the sorted corner lists (default dispatch)
     return cases
 
 
