@@ -75,8 +75,10 @@ int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int 
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::corr_fwd_supported(B, C, H, W, d, stride)) {
-        if (ws_bytes < tuned::corr_fwd_ws_bytes(B, C, H, W, d, stride)) return D2T_EWS;
-        return tuned::corr_fwd_f32(fm0, fm1, out, B, C, H, W, d, stride, ws, as_stream(stream));
+        // the workspace only enables the channel-split path of small grids (D2T_IMPL_AUTO); without it, or with
+        // D2T_IMPL_MFMA, the call runs the unsplit kernels, whose result is bit-identical to the reference
+        const bool split = impl == D2T_IMPL_AUTO && ws && ws_bytes >= tuned::corr_fwd_ws_bytes(B, C, H, W, d, stride);
+        return tuned::corr_fwd_f32(fm0, fm1, out, B, C, H, W, d, stride, split ? ws : nullptr, split ? ws_bytes : 0, as_stream(stream));
     }
     if (impl >= D2T_IMPL_MFMA) return D2T_EINVAL;     // tuned path demanded but not applicable
     return corr_fwd_generic<float>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
@@ -137,9 +139,17 @@ static int check_levels(int n, const void* const* a, const void* const* b, const
     return D2T_OK;
 }
 
+size_t d2t_corr_fwd_levels_workspace_bytes(int n, const int* C, int B, int H, int W, int d, int stride)
+{
+    if (n < 1 || n > tuned::MAXLV || !C) return 0;
+    for (int l = 0; l < n; ++l)
+        if (!tuned::corr_fwd_supported(B, C[l], H, W, d, stride)) return 0;
+    return tuned::corr_fwd_levels_ws_bytes(n, C, B, H, W);
+}
+
 int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* fm1, float* const* out, const int* C,
                             int B, int H, int W, int d, int stride, int layout, long long bstride,
-                            void*, size_t, int impl, d2t_stream_t stream)
+                            void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP16) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)out, C, B, H, W, d, stride, layout, bstride);
@@ -149,7 +159,10 @@ int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* 
                                                                      : tuned::CellLayout{cells, 1, 1LL * HW * cells};
     bool tuned_ok = impl != D2T_IMPL_GENERIC;
     for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_fwd_supported(B, C[l], H, W, d, stride);
-    if (tuned_ok) return tuned::corr_fwd_levels_f32(n, fm0, fm1, out, C, B, H, W, lay, as_stream(stream));
+    if (tuned_ok) {
+        const bool split = impl == D2T_IMPL_AUTO && ws && ws_bytes >= tuned::corr_fwd_levels_ws_bytes(n, C, B, H, W);
+        return tuned::corr_fwd_levels_f32(n, fm0, fm1, out, C, B, H, W, lay, as_stream(stream), split ? ws : nullptr, split ? ws_bytes : 0);
+    }
     if (impl >= D2T_IMPL_MFMA) return D2T_EINVAL;
     for (int l = 0; l < n; ++l) {
         rc = corr_fwd_generic<float>(fm0[l], fm1[l], out[l], B, C[l], H, W, d, stride, as_stream(stream), lay.ps, lay.cs, lay.bs);

@@ -134,9 +134,12 @@ static_assert(SG_KC * 4 * SG_NU % 64 == 0 && SG_MAXDMA <= SG_KC / 4, "DMA plan")
 // with HW_REG_HW_ID), so this also balances the matrix pipes: at 38 rows every segment has 27 tasks
 // -> 7 / 7 / 7 / 6 per SIMD.  (The first version gave wave w the fixed slots w and w+15 of a 5 x 6
 // table and issued the MFMAs of empty slots as well: 8 per SIMD.)
-__global__ void __launch_bounds__(SG_THREADS)
-k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
-               int C, int H, int W, int tiles_i, int tiles_j, int nseg, CellLayout lay)
+// fm0b / fm1b: the C channel planes this workgroup contracts over (one batch item; all of its channels, or one
+// channel range of a split -- the buffer descriptors end behind them, so the last chunk and the two staged past the
+// end arrive as zeros); outb: where the segment's cells go (the output of that batch item, or a partial-sum plane).
+__device__ __forceinline__ void
+seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* __restrict__ outb,
+         int C, int H, int W, int tiles_i, int seg, int tj, CellLayout lay)
 {
     __shared__ __attribute__((aligned(16))) float smem[SG_LDS];
 
@@ -146,16 +149,11 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
 #ifdef D2T_LAB
     if (lane == 0) { unsigned hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); lab_stamps[blockIdx.x * 32 + 16 + wave] = hw_; }
 #endif
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
     const int u0 = seg * SG_NU, nu = tiles_i - u0 < SG_NU ? tiles_i - u0 : SG_NU;
     const int j0 = tj * TP, HW = H * W;
     const unsigned plane_bytes = (unsigned)C * HW * 4u;
-    const __amdgpu_buffer_rsrc_t r1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm1 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm0 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
-    float* outb = out + (size_t)b * lay.bs;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm1b), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm0b), 0, plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ro =
         __builtin_amdgcn_make_buffer_rsrc(outb, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
 
@@ -418,6 +416,119 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
 #endif
 }
 
+__global__ void __launch_bounds__(SG_THREADS)
+k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
+               int C, int H, int W, int tiles_i, int tiles_j, int nseg, CellLayout lay)
+{
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
+    const size_t item = (size_t)b * C * H * W;
+    seg_body(fm0 + item, fm1 + item, out + (size_t)b * lay.bs, C, H, W, tiles_i, seg, tj, lay);
+}
+
+// ------------------------------------------------------------------------------------
+// Forward, channel-split ("split-K").  The real model correlates B = 1 pairs with 512 / 1024 / 2048 channels
+// (correlation_tracker.py:68-70): 38 five-tile segments for 256 CUs, and one-tile workgroups (190 of them) are bound
+// by the texture-address unit -- a 19 x 20 window per tile is 2.9x the cache lines per tile of a five-tile segment
+// (csrc/lab/ta_lab: ~2 cycles per 64-byte line touched).  So the channels of a level are split over S workgroups per
+// segment: each runs the five-tile kernel body over its channel range and writes a partial-sum plane (reference
+// layout) into the workspace; k_corr_fwd_combine adds the S planes of every cell in ascending split order --
+// deterministic, no atomics -- and writes the caller's layout.  The sum is associated differently from the
+// reference's single ascending-channel chain: results agree to f32 rounding (|delta| <= 1e-5 relative, tested), not
+// bit for bit; D2T_IMPL_GENERIC stays the bit-exact anchor and grids that fill the chip by themselves never split.
+// ------------------------------------------------------------------------------------
+struct SplitLevels {
+    const float* fm0[MAXLV]; const float* fm1[MAXLV];
+    float* part[MAXLV];                                                     // S[l] planes of B*H*W*289 floats -- or, S[l] = 1, the output itself
+    int C[MAXLV], S[MAXLV], cps[MAXLV], wg_end[MAXLV]; int n;               // cps: chunks (16 channels) per split
+};
+
+__global__ void __launch_bounds__(SG_THREADS)
+k_corr_fwd_seg_split(SplitLevels lv, int B, int H, int W, int tiles_i, int tiles_j, int nseg, CellLayout lay)
+{
+    int L = 0, wg0 = 0;
+#pragma unroll
+    for (int l = 1; l < MAXLV; ++l)
+        if (l < lv.n && (int)blockIdx.x >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
+    const float* fm0 = lv.fm0[0]; const float* fm1 = lv.fm1[0]; float* part = lv.part[0];
+    int C = lv.C[0], S = lv.S[0], cps = lv.cps[0];
+#pragma unroll
+    for (int l = 1; l < MAXLV; ++l)
+        if (L == l) { fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; part = lv.part[l]; C = lv.C[l]; S = lv.S[l]; cps = lv.cps[l]; }
+    const int nsegs = B * tiles_j * nseg;
+    const int lid = (int)blockIdx.x - wg0, s = lid / nsegs, bid = xcd_remap(lid - s * nsegs, nsegs);
+    const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
+    const int HW = H * W, c0 = s * cps * SG_KC;
+    const int cn = C - c0 < cps * SG_KC ? C - c0 : cps * SG_KC;      // channels of this split (>= 1 by construction)
+    const size_t item = ((size_t)b * C + c0) * HW;
+    const CellLayout ref{CELLS, 1, 1LL * HW * CELLS};
+    if (S == 1) seg_body(fm0 + item, fm1 + item, part + (size_t)b * lay.bs, cn, H, W, tiles_i, seg, tj, lay);   // a level that is not split
+    else seg_body(fm0 + item, fm1 + item, part + ((size_t)s * B + b) * HW * CELLS, cn, H, W, tiles_i, seg, tj, ref);
+}
+
+// out[cell of pixel] = sum over the splits, ascending.  One workgroup = (level, batch item, 16 consecutive pixels):
+// the 16 x 289 partial sums of a split are one contiguous run (all S loads of an element are issued together); the
+// channel-major layout goes through LDS so that a cell's 16 pixels leave as one 64-byte run.
+constexpr int CB_PIX = 16;
+constexpr int CB_MAXS = 8;                                           // most splits of a level (fwd_split_plan)
+struct CombineLevels { const float* part[MAXLV]; float* out[MAXLV]; int S[MAXLV]; int n; };
+
+__global__ void __launch_bounds__(256)
+k_corr_fwd_combine(CombineLevels lv, int B, int HW, CellLayout lay)
+{
+    __shared__ float tile[CB_PIX * (CELLS + 1)];
+    const int L = blockIdx.z, b = blockIdx.y, p0 = blockIdx.x * CB_PIX;
+    const float* part = lv.part[0]; float* out = lv.out[0]; int S = lv.S[0];
+#pragma unroll
+    for (int l = 1; l < MAXLV; ++l)
+        if (L == l) { part = lv.part[l]; out = lv.out[l]; S = lv.S[l]; }
+    if (S == 1) return;                                              // written in place by the segment kernel
+    const int np = HW - p0 < CB_PIX ? HW - p0 : CB_PIX, nel4 = np * CELLS / 4;   // CB_PIX * 289 floats = 1156 whole float4
+    const size_t plane = (size_t)B * HW * CELLS;
+    const float* src = part + ((size_t)b * HW + p0) * CELLS;          // dword-aligned 16-byte accesses (H*W*289 need not be a multiple of 4)
+    float* dst = out + (size_t)b * lay.bs;
+    auto sum_at = [&](int e) {
+        f32x4 v[CB_MAXS];
+#pragma unroll
+        for (int s = 0; s < CB_MAXS; ++s)
+            v[s] = s < S ? f32x4(*reinterpret_cast<const f32x4u*>(src + s * plane + 4 * e)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a = v[0];
+#pragma unroll
+        for (int s = 1; s < CB_MAXS; ++s) a = s < S ? a + v[s] : a;  // ascending split order
+        return a;
+    };
+    const int tail0 = nel4 * 4, ntail = np * CELLS - tail0;          // np < 16 (last block of the map): up to 3 floats left
+    auto sum_tail = [&](int e) {
+        const float* sp = part + ((size_t)b * HW + p0) * CELLS + e;
+        float a = sp[0];
+        for (int s = 1; s < S; ++s) a += sp[s * plane];
+        return a;
+    };
+    if (lay.cs == 1) {                                               // reference layout: element-wise
+        float* d = dst + (size_t)p0 * CELLS;
+        for (int e = threadIdx.x; e < nel4; e += 256) *reinterpret_cast<f32x4u*>(d + 4 * e) = sum_at(e);
+        if ((int)threadIdx.x < ntail) dst[(size_t)p0 * CELLS + tail0 + threadIdx.x] = sum_tail(tail0 + threadIdx.x);
+        return;
+    }
+    for (int e = threadIdx.x; e < nel4; e += 256) {
+        const f32x4 a = sum_at(e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = 4 * e + k, p = f / CELLS, c = f - p * CELLS;
+            tile[p * (CELLS + 1) + c] = a[k];
+        }
+    }
+    if ((int)threadIdx.x < ntail) {
+        const int f = tail0 + threadIdx.x, p = f / CELLS, c = f - p * CELLS;
+        tile[p * (CELLS + 1) + c] = sum_tail(f);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CELLS * CB_PIX; e += 256) {
+        const int c = e / CB_PIX, p = e - c * CB_PIX;
+        if (p < np) dst[(size_t)c * lay.cs + (size_t)(p0 + p) * lay.ps] = tile[p * (CELLS + 1) + c];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Forward, small grids (the real model's B = 1 pairs: 160-190 p-tiles in all).  Same LDS-staged
 // scheme as k_corr_fwd_seg with short segments (NU = 1 or 2 p-tiles, 3*NU waves) so that every CU
@@ -677,13 +788,55 @@ bool corr_fwd_supported(int B, int C, int H, int W, int d, int s)
     return blocks <= 0x7fffffffLL && offsets_fit;
 }
 
-size_t corr_fwd_ws_bytes(int, int, int, int, int, int) { return 0; }
+// Channel-split plan of a small-grid call (fewer than 192 five-tile segments): S[l] splits of cps[l] 16-channel chunks
+// per level, S = 0 everywhere when the call does not split.  Splitting pays when a workgroup keeps enough chunks to
+// amortise the five-tile kernel's prologue and epilogue (~12 us): measured crossover at B = 1, 38 x 75 between 512 and
+// 768 channels (one-tile kernel 27 / 48 / 117 us at C = 512 / 1024 / 2048).
+struct SplitPlan { int S[MAXLV], cps[MAXLV]; bool on; size_t ws_bytes; };
+
+static SplitPlan fwd_split_plan(int nl, const int* C, int B, int H, int W)
+{
+    SplitPlan p;
+    p.on = false; p.ws_bytes = 0;
+    for (int l = 0; l < MAXLV; ++l) { p.S[l] = 0; p.cps[l] = 0; }
+    const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
+    const int nseg = (tiles_i + SG_NU - 1) / SG_NU;
+    const long long segs = 1LL * B * tiles_j * nseg;
+    if (segs >= 192 || nl < 1 || nl > MAXLV) return p;
+    int budget = (int)(256 / segs);                                  // splits in all: one round of workgroups, one per CU
+    budget = budget > nl - 1 + CB_MAXS ? nl - 1 + CB_MAXS : budget;  // (k_corr_fwd_combine adds at most CB_MAXS planes)
+    int chunks[MAXLV], total = 0, most = 0;
+    for (int l = 0; l < nl; ++l) { chunks[l] = (C[l] + SG_KC - 1) / SG_KC; total += chunks[l]; most = chunks[l] > most ? chunks[l] : most; }
+    if (budget < nl + 1 || total < 40 || most < 40) return p;        // nothing to gain below ~640 channels
+    int S[MAXLV];
+    for (int l = 0; l < nl; ++l) S[l] = 1;
+    for (int used = nl; used < budget; ++used) {                     // next split to the level with the longest workgroups
+        int best = 0;
+        for (int l = 1; l < nl; ++l)
+            if (1LL * chunks[l] * S[best] > 1LL * chunks[best] * S[l]) best = l;
+        if ((chunks[best] + S[best]) / (S[best] + 1) < 8 || S[best] >= CB_MAXS) break;   // keep >= 8 chunks per workgroup
+        ++S[best];
+    }
+    for (int l = 0; l < nl; ++l) {
+        p.cps[l] = (chunks[l] + S[l] - 1) / S[l];
+        p.S[l] = (chunks[l] + p.cps[l] - 1) / p.cps[l];              // no empty split
+        p.ws_bytes += (size_t)p.S[l] * B * H * W * CELLS * sizeof(float);
+    }
+    p.on = true;
+    return p;
+}
+
+size_t corr_fwd_levels_ws_bytes(int nl, const int* C, int B, int H, int W) { return fwd_split_plan(nl, C, B, H, W).ws_bytes; }
+size_t corr_fwd_ws_bytes(int B, int C, int H, int W, int d, int s)
+{
+    return corr_fwd_supported(B, C, H, W, d, s) ? corr_fwd_levels_ws_bytes(1, &C, B, H, W) : 0;
+}
 
 // nl problems of one spatial shape (B, H, W), level l with C[l] channels.  Small grids (the model's
 // B = 1 pairs) go out as ONE launch, heaviest level first; grids that fill the chip by themselves are
 // launched one after the other.
 int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1, float* const* out, const int* C,
-                        int B, int H, int W, CellLayout lay, hipStream_t st)
+                        int B, int H, int W, CellLayout lay, hipStream_t st, void* ws, size_t ws_bytes)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     const int nseg = (tiles_i + SG_NU - 1) / SG_NU;
@@ -692,6 +845,32 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
         for (int l = 0; l < nl; ++l)
             hipLaunchKernelGGL(k_corr_fwd_seg, dim3((int)strip_blocks), dim3(SG_THREADS), 0, st,
                                fm0[l], fm1[l], out[l], C[l], H, W, tiles_i, tiles_j, nseg, lay);
+        return launch_status();
+    }
+    const SplitPlan plan = fwd_split_plan(nl, C, B, H, W);
+    if (plan.on && ws && ws_bytes >= plan.ws_bytes) {                // channel split (a caller without workspace gets the kernels below)
+        SplitLevels sl;
+        CombineLevels cl;
+        sl.n = cl.n = nl;
+        float* w = static_cast<float*>(ws);
+        int end = 0;
+        for (int l = 0; l < MAXLV; ++l) {
+            const int src = l < nl ? l : nl - 1;
+            sl.fm0[l] = fm0[src]; sl.fm1[l] = fm1[src]; sl.C[l] = C[src]; sl.S[l] = plan.S[src]; sl.cps[l] = plan.cps[src];
+            if (l < nl) {
+                sl.part[l] = plan.S[l] == 1 ? out[l] : w;            // an unsplit level writes its output directly
+                if (plan.S[l] > 1) w += (size_t)plan.S[l] * B * H * W * CELLS;
+                end += (int)strip_blocks * plan.S[l];
+            } else {
+                sl.part[l] = sl.part[nl - 1];
+            }
+            sl.wg_end[l] = end;
+            cl.part[l] = sl.part[l]; cl.out[l] = out[src]; cl.S[l] = plan.S[src];
+        }
+        hipLaunchKernelGGL(k_corr_fwd_seg_split, dim3(end), dim3(SG_THREADS), 0, st, sl, B, H, W, tiles_i, tiles_j, nseg, lay);
+        int rc = launch_status();
+        if (rc != D2T_OK) return rc;
+        hipLaunchKernelGGL(k_corr_fwd_combine, dim3((H * W + CB_PIX - 1) / CB_PIX, B, nl), dim3(256), 0, st, cl, B, H * W, lay);
         return launch_status();
     }
     int order[MAXLV];
@@ -719,10 +898,10 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
 }
 
 int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int, int,
-                 void*, hipStream_t st)
+                 void* ws, size_t ws_bytes, hipStream_t st)
 {
     const CellLayout lay{CELLS, 1, 1LL * H * W * CELLS};
-    return corr_fwd_levels_f32(1, &fm0, &fm1, &out, &C, B, H, W, lay, st);
+    return corr_fwd_levels_f32(1, &fm0, &fm1, &out, &C, B, H, W, lay, st, ws, ws_bytes);
 }
 
 // ====================================================================================

@@ -12,13 +12,14 @@ namespace d2t { namespace tuned {
 bool   corr_fwd_supported(int B, int C, int H, int W, int d, int s);
 size_t corr_fwd_ws_bytes(int B, int C, int H, int W, int d, int s);
 int    corr_fwd_f32(const float* fm0, const float* fm1, float* out,
-                    int B, int C, int H, int W, int d, int s, void* ws, hipStream_t st);
+                    int B, int C, int H, int W, int d, int s, void* ws, size_t ws_bytes, hipStream_t st);
 
 // Cell (ci,cj) of pixel (i,j) of batch item b at b*bs + (i*W+j)*ps + (ci*17+cj)*cs floats (see d2t_corr_tuned.hip)
 struct CellLayout { int ps, cs; long long bs; };
 constexpr int MAXLV = 4;
+size_t corr_fwd_levels_ws_bytes(int nl, const int* C, int B, int H, int W);
 int    corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1, float* const* out, const int* C,
-                           int B, int H, int W, CellLayout lay, hipStream_t st);
+                           int B, int H, int W, CellLayout lay, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 int    corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
                            float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
                            int bwd_variant = 0);

@@ -151,9 +151,10 @@ def pointwise_correlation_levels_forward(FM0s, FM1s, d_max: int, stride: int, ou
                 raise RuntimeError(f"out must be float32 (B, >= {c0 + L * cells}, H, W), got {tuple(buf.shape)}")
         outs = [buf[:, c0 + l * cells: c0 + (l + 1) * cells] for l in range(L)]
         Cs = (ctypes.c_int * L)(*[int(a.shape[1]) for a in FM0s])
+        ws, n = _workspace(_native.lib.d2t_corr_fwd_levels_workspace_bytes(L, Cs, B, H, W, d_max, stride), FM0s[0])
         rc = _native.lib.d2t_corr_fwd_levels_f32(
             L, _ptr_array(FM0s), _ptr_array(FM1s), _ptr_array(outs), Cs, B, H, W, d_max, stride,
-            _native.LAYOUT_CHANNEL_MAJOR, buf.shape[1] * H * W, 0, 0, impl, _stream(FM0s[0]))
+            _native.LAYOUT_CHANNEL_MAJOR, buf.shape[1] * H * W, _ptr(ws), n, impl, _stream(FM0s[0]))
     _native.check(rc, "pointwise_correlation_levels_forward")
     return buf
 

@@ -77,7 +77,9 @@ for _n in ("roipool_fwd", "roipool_bwd", "psroipool_fwd", "psroipool_bwd"):
 _proto("d2t_corr_fwd_levels_f32", _I, [_I, _P, _P, _P, _P] + [_I] * 5 + [_I, ctypes.c_longlong, _P, _Z, _I, _P])
 # (n, gout[], fm0[], fm1[], gfm0[], gfm1[], C[], B,H,W,d,stride, layout, batch_stride, ws, ws_bytes, impl, stream)
 _proto("d2t_corr_bwd_levels_f32", _I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 5 + [_I, ctypes.c_longlong, _P, _Z, _I, _P])
-SYMBOLS += ["d2t_corr_fwd_levels_f32", "d2t_corr_bwd_levels_f32"]
+# (n, C[], B,H,W,d,stride)
+_proto("d2t_corr_fwd_levels_workspace_bytes", _Z, [_I, _P] + [_I] * 5)
+SYMBOLS += ["d2t_corr_fwd_levels_f32", "d2t_corr_bwd_levels_f32", "d2t_corr_fwd_levels_workspace_bytes"]
 LAYOUT_REFERENCE, LAYOUT_CHANNEL_MAJOR = 0, 1
 _proto("d2t_psroipool_channels", _I, [_P, _I, _I, _P])
 _proto("d2t_corr_mask", _I, [_P, _I, _I, _I, _I, _P])

@@ -105,9 +105,16 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1,
  *   D2T_LAYOUT_CHANNEL_MAJOR  cell (ci,cj) of pixel (i,j) of item b at
  *                             out[l][b*batch_stride + (ci*(2d+1)+cj)*H*W + i*W + j]:
  *                             out[l] may point into a wider (channels,H,W) buffer
- * Values are bit-identical to d2t_corr_fwd_f32 / d2t_corr_bwd_f32 on the same inputs.
+ * Values equal those of d2t_corr_fwd_f32 / d2t_corr_bwd_f32 on the same inputs (bit for bit where neither call
+ * splits channels, see d2t_corr_fwd_levels_workspace_bytes).
  * Arrays of pointers / channel counts are HOST arrays of n_levels entries.                      */
 enum { D2T_LAYOUT_REFERENCE = 0, D2T_LAYOUT_CHANNEL_MAJOR = 1 };
+
+/* Scratch that lets small-grid calls (the model's B = 1 pairs with 1024 / 2048 channels) split the channels of a level
+ * over several workgroups and add the partial sums in a fixed order (deterministic; agrees with the unsplit result to
+ * f32 rounding, not bit for bit).  Optional: with ws = NULL / too small, or impl = D2T_IMPL_MFMA, the unsplit kernels
+ * run (bit-identical to the reference).  0 when the call would not split.  C: HOST array of n_levels entries. */
+size_t d2t_corr_fwd_levels_workspace_bytes(int n_levels, const int* C, int B, int H, int W, int d, int stride);
 
 int d2t_corr_fwd_levels_f32(int n_levels, const float* const* fm0, const float* const* fm1, float* const* out,
                             const int* C, int B, int H, int W, int d, int stride,

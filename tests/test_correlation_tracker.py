@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+MFMA = 2                                                                     # D2T_IMPL_MFMA: tuned kernels, never channel-split
+
+
+def _splits(Cs, B, H, W, d, s):
+    import ctypes
+    from detect_to_track.models import _native
+    return _native.lib.d2t_corr_fwd_levels_workspace_bytes(len(Cs), (ctypes.c_int * len(Cs))(*Cs), B, H, W, d, s) > 0
+
+
 def _unfused(fm0s, fm1s, d, s, impl=0):
     from detect_to_track.models import _ext
     outs = []
@@ -42,9 +51,17 @@ def test_levels_forward_backward_equal_unfused(case):
     g = torch.Generator().manual_seed(sum(Cs) * 131 + H)
     fm0s = [torch.rand(B, C, H, W, generator=g).to(DEV) for C in Cs]
     fm1s = [torch.rand(B, C, H, W, generator=g).to(DEV) for C in Cs]
-    want = _unfused(fm0s, fm1s, d, s)
+    want = _unfused(fm0s, fm1s, d, s, MFMA if d == 8 and s == 1 and W >= 20 else 0)   # unsplit kernels: the reference's chain, bit for bit
     got = _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s)
-    assert got.shape == want.shape and torch.equal(got, want)
+    assert got.shape == want.shape
+    if _splits(Cs, B, H, W, d, s):
+        # channels split over workgroups, partial sums added in a fixed order: same terms, other association
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+        assert torch.equal(got, _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s))          # deterministic
+        assert torch.equal(_ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s, impl=MFMA), want)   # opt out: bit-exact
+        want = got
+    else:
+        assert torch.equal(got, want)
     # into the middle of a wider buffer (a torch.cat target), neighbours untouched
     pad0, pad1 = 5, 3
     buf = torch.full((B, pad0 + len(Cs) * cells + pad1, H, W), -7.0, device=DEV)
@@ -57,7 +74,15 @@ def test_levels_forward_backward_equal_unfused(case):
     for l, (a, b) in enumerate(zip(fm0s, fm1s)):
         gl = gbuf[:, pad0 + l * cells: pad0 + (l + 1) * cells].permute(0, 2, 3, 1).reshape(B, H, W, 2 * d + 1, 2 * d + 1)
         r0, r1 = _ext.pointwise_correlation_backward(gl.contiguous(), a, b, d, s)
-        assert torch.equal(g0[l], r0) and torch.equal(g1[l], r1)
+        # Same terms either way; bit-equal where both calls run the same kernel.  Where the 256-channel grid of a level
+        # fills >= 100 CUs the reference-layout call takes the 8-wave strip kernel (d2t_corr_bwd8.hip) and the
+        # channel-major call the 16-wave one, which enumerate a tile's window slots in a different order: 1e-5 of the
+        # gradient's scale (both are held to the oracle in test_levels_backward_matches_oracle / test_matches_oracle).
+        if 2 * B * ((W + 3) // 4) * ((a.shape[1] + 255) // 256) >= 100 and d == 8 and s == 1 and H >= 17:
+            for x, y in ((g0[l], r0), (g1[l], r1)):
+                torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-5 * float(y.abs().max()))
+        else:
+            assert torch.equal(g0[l], r0) and torch.equal(g1[l], r1)
 
 
 def test_levels_match_oracle(oracle):

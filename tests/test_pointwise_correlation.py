@@ -78,6 +78,28 @@ CASES = [  # (B, C, H, W, d, s)
 ]
 
 
+@pytest.mark.parametrize("case", [(1, 1040, 38, 75), (2, 800, 21, 44), (1, 2048, 38, 75)], ids=str)
+def test_channel_split_forward(case, oracle):
+    """Small grids with many channels (the model's B = 1 pairs, correlation_tracker.py:68-70) split the channels of a
+    call over several workgroups and add the partial sums in a fixed order.  Same terms as the reference's chain
+    (pointwise_correlation_cuda.cu:105-107), other association: within 1e-5 of the oracle, deterministic, structural
+    zeros exact; D2T_IMPL_MFMA opts out and is bit-identical to the oracle."""
+    import ctypes
+    from detect_to_track.models import _ext, _native
+    B, C, H, W = case
+    assert _native.lib.d2t_corr_fwd_workspace_bytes(B, C, H, W, 8, 1, 4) > 0, "this shape is meant to split"
+    rng = np.random.default_rng(C + H)
+    fm0, fm1 = rng.random((B, C, H, W), dtype=np.float32), rng.standard_normal((B, C, H, W)).astype(np.float32)
+    want = oracle.corr_fwd(fm0, fm1, 8, 1)
+    got = _ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1)
+    # sum |terms| <= sum |fm0||fm1| ~ 0.4 C: 1e-5 of the magnitude scale of an element
+    np.testing.assert_allclose(_n(got), want, rtol=1e-5, atol=1e-5 * 0.4 * C)
+    mask = oracle.corr_mask(H, W, 8, 1).astype(bool)
+    assert not _n(got)[:, ~mask].any()                                 # structural zeros are exact zeros
+    assert torch.equal(got, _ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1))
+    np.testing.assert_array_equal(_n(_ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1, 2)), want)
+
+
 @pytest.mark.parametrize("impl", [0, 1], ids=["auto", "generic"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
