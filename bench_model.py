@@ -4,10 +4,12 @@
 What is timed: the reference's training step (trainer.py:133-256, 270-281) for a minibatch of B frame
 pairs -- backbone on the two frames of a pair, RPN, R-FCN on both frames' regions, correlation tracker,
 the five losses summed over the minibatch, ONE backward, one SGD step -- with random weights and synthetic
-frames (there is no network for datasets or checkpoints).  What is NOT the reference's: the host-side
-label encoders, anchor decoding and NMS (numpy + third-party code) are replaced by
-fixed synthetic regions and targets of the same shapes, and the losses by plain smooth-L1 / NLL terms; the
-ops, their shapes and their call pattern are the reference's.
+frames (there is no network for datasets or checkpoints).  The step itself is detect_to_track/training.py
+(DataParallelTrainer over a SyntheticPairManager): region proposals are decoded, filtered and NMS-ed ON THE DEVICE
+from the live RPN outputs (csrc/d2t_regions.hip -- the reference does this on host copies, trainer.py:178-207:
+no device->host copy is left between the RPN and R-FCN); what is NOT the reference's are the host-side label
+encoders (numpy + third-party code, SURVEY §2 rows 13-15: synthetic targets of the same shapes) and the loss classes
+(plain smooth-L1 / NLL terms); the ops, their shapes and their call pattern are the reference's.
 
 The deliverable is the step-time breakdown: which part of a step the three custom ops
 (PointwiseCorrelation, ROIPool, PSROIPool) are.  Every call into the HIP library is bracketed by HIP
@@ -60,20 +62,11 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
-def random_rois(R, seed):
-    """(R, 4) ijhw fractions, boxes INSIDE the frame: ROIPool gives 0/0 = NaN for a bin that lies outside the map
-    (like the reference, roipool_cuda.cu:61), and the trainer's tracked boxes are ground-truth boxes."""
-    rng = np.random.default_rng(seed)
-    ctr = rng.uniform(0.15, 0.85, (R, 2))
-    size = np.minimum(rng.uniform(0.05, 0.6, (R, 2)), 1.9 * np.minimum(ctr, 1.0 - ctr))
-    return np.concatenate([ctr, size], 1).astype(np.float32)
-
-
 class OpTimer:
     """Brackets every tensor-level entry point of the HIP library with events on the current stream."""
     NAMES = ("pointwise_correlation_forward", "pointwise_correlation_backward",
              "pointwise_correlation_levels_forward", "pointwise_correlation_levels_backward",
-             "roipool_forward", "roipool_backward", "ps_roipool_forward", "ps_roipool_backward")
+             "roipool_forward", "roipool_backward", "ps_roipool_forward", "ps_roipool_backward", "region_filter")
 
     def __init__(self, ext):
         self.pending = []
@@ -148,69 +141,28 @@ def main(argv=None):
     torch.manual_seed(1 + rank)                                                    # every rank its own frames
 
     H, W, B, R, Rt = args.height, args.width, args.pairs, args.rois, args.track_rois
-    frames = [torch.rand(2, 3, H, W, device=dev) for _ in range(B)]
+    from detect_to_track.training import BatchLoader, DataParallelTrainer, RegionProposals, SyntheticPairManager, build_anchors
     with torch.no_grad():
-        fh, fw = model.backbone(frames[0][:1])["c4"].shape[-2:]
-    n_anchor = fh * fw * 15
-    rois = [[torch.from_numpy(random_rois(R, 10 * i + t)).to(dev) for t in (0, 1)] for i in range(B)]
-    trois = [torch.from_numpy(random_rois(Rt, 100 + i)).to(dev) for i in range(B)]
-    o_star = [torch.randint(0, 2, (2, n_anchor), device=dev) for _ in range(B)]
-    b_star = [torch.randn(2, n_anchor, 4, device=dev) for _ in range(B)]
-    c_star = [torch.randint(0, 31, (2 * R,), device=dev) for _ in range(B)]
-    r_star = [torch.randn(2 * R, 4, device=dev) for _ in range(B)]
-    t_star = [torch.randn(Rt, 4, device=dev) for _ in range(B)]
-    sl1 = torch.nn.functional.smooth_l1_loss
-    nll = torch.nn.functional.nll_loss
-
-    sections = ("backbone", "rpn", "rcnn", "tracker", "loss")
+        fh, fw = model.backbone(torch.rand(1, 3, H, W, device=dev))["c4"].shape[-2:]
+    anchors = build_anchors((fh, fw), [0.001, 0.004, 0.016, 0.064, 0.256], [0.5, 1.0, 2.0])     # cfg/default.yaml:13-14
+    n_anchor = len(anchors)
+    # cfg/default.yaml:21-23: confidence 0.3, NMS IoU 0.5; the list is capped at R regions per frame (BASELINE config 3: 300)
+    regions = RegionProposals(anchors, 0.3, R, 0.5, dev)
+    n_steps = args.warmup + args.steps
+    manager = SyntheticPairManager(world * B * n_steps, (H, W), n_anchor, R, Rt, 30, dev, seed=1)
+    loader = iter(BatchLoader(manager, B, rank, world, seed=0))                  # every rank its own pairs
+    trainer = DataParallelTrainer(model, optim, coefs, regions, buckets)
+    sections = DataParallelTrainer.SECTIONS
 
     def step(record):
-        """One minibatch: forward of every pair, one backward, one optimizer step.  `record` collects
-        (section, start event, end event) of the forward parts."""
+        """One minibatch (training.py: forward of every pair, one backward, gradient all-reduce, one optimizer step)."""
         def mark():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             return e
-        total = torch.zeros(5, device=dev)
-        ev = []
-        for i in range(B):
-            t0 = mark()
-            fmaps = model.backbone(frames[i])                                     # trainer.py:152
-            t1 = mark()
-            o_hat, b_hat, fm_reg = model.rpn(fmaps["c4"])                         # :164
-            t2 = mark()
-            c5_0, c5_1 = fmaps["c5"]
-            c0, b0 = model.rcnn(c5_0, rois[i][0])                                 # :207-208
-            c1, b1 = model.rcnn(c5_1, rois[i][1])
-            t3 = mark()
-            pyr0 = OrderedDict((k, fmaps[k][0]) for k in ("c3", "c4", "c5"))
-            pyr1 = OrderedDict((k, fmaps[k][1]) for k in ("c3", "c4", "c5"))
-            t_hat = model.c_tracker(pyr0, pyr1, fm_reg[0], fm_reg[1], trois[i])   # :238
-            t4 = mark()
-            c_hat, r_hat = torch.cat([c0, c1]), torch.cat([b0, b1])
-            losses = torch.stack([
-                nll(torch.log(o_hat.reshape(-1, 2) + 1e-8), o_star[i].reshape(-1)),
-                sl1(b_hat, b_star[i]),
-                nll(torch.log(c_hat + 1e-8), c_star[i]),
-                sl1(r_hat, r_star[i]),
-                sl1(t_hat, t_star[i]),
-            ])
-            total = total + losses
-            t5 = mark()
-            ev.append((t0, t1, t2, t3, t4, t5))
-        if buckets is not None:
-            buckets.zero_grad()                                                    # gradients live in (and stay attached to) the buckets
-        else:
-            optim.zero_grad(set_to_none=True)
-        b0e = mark()
-        total.backward(coefs)                                                      # :276
-        if buckets is not None:
-            buckets.wait()                                                         # the all-reduces ran under the backward pass
-        b1e = mark()
-        optim.step()
-        b2e = mark()
+        total, stamps, (b0e, b1e, b2e) = trainer.train_step(next(loader), mark)
         if record is not None:
-            record.append((ev, b0e, b1e, b2e))
+            record.append((stamps, b0e, b1e, b2e))
         return total
 
     if rank == 0:
@@ -240,7 +192,7 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         step_ms = float(t.item())
     with torch.no_grad():                                                         # the ops' cold non-finite paths must not be what was timed
-        fm = model.backbone(frames[0])
+        fm = model.backbone(manager[0].frames)
         amax = {k: float(v.abs().max()) for k, v in fm.items()}
     finite = all(np.isfinite(v) for v in amax.values()) and all(bool(torch.isfinite(p).all()) for p in params)
     if rank == 0:
@@ -258,7 +210,8 @@ def main(argv=None):
     calls = {k: v // args.steps for k, v in calls.items()}
     fam = {"correlation": sum(v for k, v in ops.items() if k.startswith("pointwise")),
            "roipool": sum(v for k, v in ops.items() if k.startswith("roipool")),
-           "ps_roipool": sum(v for k, v in ops.items() if k.startswith("ps_roipool"))}
+           "ps_roipool": sum(v for k, v in ops.items() if k.startswith("ps_roipool")),
+           "region_filter": ops.get("region_filter", 0.0)}
     ops_ms = sum(fam.values())
     line = {
         "bench": "DetectTrack training step (BASELINE config %d)" % (4 if world == 1 else 5), "n_gpus": world, "scaling": "weak",
@@ -270,6 +223,7 @@ def main(argv=None):
         "sections_ms": sec,
         "custom_ops_ms": ops, "custom_ops_calls_per_step": calls, "custom_ops_by_family_ms": fam,
         "custom_ops_ms_total": ops_ms, "custom_ops_frac_of_step": ops_ms / step_ms,
+        "regions": "device (d2t_region_filter_f32 on the live RPN outputs: no device->host copy between RPN and R-FCN)",
         "note": "sections are forward parts per step (all pairs); custom_ops_* are HIP-event brackets around every call "
                 "into libd2t_ops.so (forward and backward), measured inside the running step",
     }

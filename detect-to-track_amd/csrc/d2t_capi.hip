@@ -359,4 +359,27 @@ int d2t_corr_mask(uint8_t* mask, int H, int W, int d, int stride, d2t_stream_t s
     return corr_mask(mask, H, W, d, stride, as_stream(stream));
 }
 
+// ------------------------------------------------------------------ region proposals
+size_t d2t_region_filter_workspace_bytes(int A, int max_dets) { return region_filter_ws_bytes(A, max_dets); }
+
+int d2t_region_filter_f32(const float* anchors, const float* offsets, const float* confs, int A,
+                          float conf_thresh, int max_dets, float iou_thresh,
+                          float* out_boxes, float* out_conf, int32_t* out_idx, int32_t* out_count,
+                          void* ws, size_t ws_bytes, d2t_stream_t stream)
+{
+    if (A < 0 || max_dets < 1 || max_dets > region_max_dets() || !out_boxes || !out_conf || !out_idx || !out_count) return D2T_EINVAL;
+    if (A > 0 && (!anchors || !offsets || !confs)) return D2T_EINVAL;
+    if (!fits_i32(4LL * A)) return D2T_ETOOBIG;
+    if (A == 0) {                                                    // nothing to filter: an all-padding list
+        hipError_t e = hipMemsetAsync(out_boxes, 0, (size_t)max_dets * 16, as_stream(stream));
+        if (e == hipSuccess) e = hipMemsetAsync(out_conf, 0, (size_t)max_dets * 4, as_stream(stream));
+        if (e == hipSuccess) e = hipMemsetAsync(out_idx, 0xff, (size_t)max_dets * 4, as_stream(stream));
+        if (e == hipSuccess) e = hipMemsetAsync(out_count, 0, 4, as_stream(stream));
+        return e == hipSuccess ? D2T_OK : static_cast<int>(e);
+    }
+    if (!ws || ws_bytes < region_filter_ws_bytes(A, max_dets)) return D2T_EWS;
+    return region_filter_f32(anchors, offsets, confs, A, conf_thresh, max_dets, iou_thresh, out_boxes, out_conf, out_idx, out_count,
+                             ws, as_stream(stream));
+}
+
 }  // extern "C"

@@ -29,4 +29,11 @@ template <typename T> int psroipool_bins(const T* rois, int32_t* bounds, int R, 
 int psroipool_channels(int32_t* ch, int nT, int k, hipStream_t st);
 int corr_mask(uint8_t* mask, int H, int W, int d, int s, hipStream_t st);
 
+// ---- region proposals on the device (d2t_regions.hip): decode + confidence filter + top-k + greedy NMS
+size_t region_filter_ws_bytes(int A, int max_dets);
+int region_max_dets();
+int region_filter_f32(const float* anchors, const float* offsets, const float* confs, int A,
+                      float conf_thresh, int max_dets, float iou_thresh,
+                      float* out_boxes, float* out_conf, int* out_idx, int* out_count, void* ws, hipStream_t st);
+
 }  // namespace d2t

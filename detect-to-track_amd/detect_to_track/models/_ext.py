@@ -298,3 +298,33 @@ def pointwise_correlation_mask(i_h: int, i_w: int, d_max: int, stride: int, devi
                                        torch.cuda.current_stream(dev).cuda_stream)
     _native.check(rc, "corr_mask")
     return out
+
+
+def region_filter(anchors: Tensor, offsets: Tensor, confs: Tensor, conf_thresh: float, max_dets: int, iou_thresh: float):
+    """RPN outputs -> region proposals without leaving the device (reference trainer.py:178-190: numpy
+    frcnn_box_decode + ConfidenceFilter + MaxDetFilter + NMSFilter on host copies).
+
+    anchors, offsets (A,4), confs (A,): float32 CUDA.  Returns (boxes (max_dets,4), confs (max_dets,),
+    anchor_index (max_dets,) int32, count (1,) int32): survivors first, in descending confidence, then padding
+    (zero boxes, index -1).  Nothing is read back: shapes are static."""
+    for t, name in ((anchors, "anchors"), (offsets, "offsets"), (confs, "confs")):
+        _check_input(t, name)
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{name} must be float32")
+        _same(t, anchors, name, "anchors")
+    A = int(confs.numel())
+    if tuple(anchors.shape) != (A, 4) or tuple(offsets.shape) != (A, 4):
+        raise RuntimeError(f"anchors / offsets must be ({A}, 4), got {tuple(anchors.shape)} / {tuple(offsets.shape)}")
+    max_dets = int(max_dets)
+    dev = anchors.device
+    with torch.cuda.device(dev):
+        boxes = torch.empty((max_dets, 4), dtype=torch.float32, device=dev)
+        conf = torch.empty((max_dets,), dtype=torch.float32, device=dev)
+        idx = torch.empty((max_dets,), dtype=torch.int32, device=dev)
+        count = torch.empty((1,), dtype=torch.int32, device=dev)
+        ws, n = _workspace(_native.lib.d2t_region_filter_workspace_bytes(A, max_dets), anchors)
+        rc = _native.lib.d2t_region_filter_f32(anchors.data_ptr(), offsets.data_ptr(), confs.data_ptr(), A, float(conf_thresh),
+                                               max_dets, float(iou_thresh), boxes.data_ptr(), conf.data_ptr(), idx.data_ptr(),
+                                               count.data_ptr(), _ptr(ws), n, _stream(anchors))
+    _native.check(rc, "region_filter")
+    return boxes, conf, idx, count

@@ -175,6 +175,23 @@ int d2t_psroipool_bins_f64(const double* rois, int32_t* bounds, int R, int H, in
 int d2t_psroipool_channels(int32_t* channels, int nT, int k, d2t_stream_t stream);
 int d2t_corr_mask(uint8_t* mask, int H, int W, int d, int stride, d2t_stream_t stream);
 
+/* ---------------- region proposals: decode + confidence filter + top-k + NMS on the device ----------------
+ * Replaces the host round trip between the RPN and the R-FCN heads (reference trainer.py:178-207,
+ * inference.py:78-91): anchors + offsets -> boxes (data/encoding.py:182-206, frcnn_box_decode), then the three
+ * `ml_utils` filters the reference composes -- ConfidenceFilter(conf_thresh), MaxDetFilter(max_dets),
+ * NMSFilter(iou_thresh) (trainer.py:98-102) -- restated as: keep conf > conf_thresh; keep the max_dets highest
+ * confidences (ties: lower anchor index first); greedy NMS in descending confidence, a kept box removes every later
+ * box with IoU > iou_thresh.  (`ml_utils` is not vendored with the reference: parity for the filters is unpinned.)
+ *   anchors, offsets (A,4); confs (A): device, float32; boxes are (centre_i, centre_j, height, width) fractions.
+ *   out_boxes (max_dets,4), out_conf (max_dets), out_idx (max_dets, anchor index or -1), out_count (1): device.
+ *   Survivors come first, in descending confidence; the rest of the lists is padding (zero boxes, index -1), so the
+ *   caller can keep static shapes and never reads the count back.  max_dets <= 4096.                            */
+size_t d2t_region_filter_workspace_bytes(int A, int max_dets);
+int d2t_region_filter_f32(const float* anchors, const float* offsets, const float* confs, int A,
+                          float conf_thresh, int max_dets, float iou_thresh,
+                          float* out_boxes, float* out_conf, int32_t* out_idx, int32_t* out_count,
+                          void* ws, size_t ws_bytes, d2t_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

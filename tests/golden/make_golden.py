@@ -38,6 +38,17 @@ import d2t_ref_psroipool as ref_ps       # noqa: E402
 import d2t_ref_roipool as ref_roi        # noqa: E402
 
 DEV = "cuda:0"
+# sha256 of the reference sources (and of oracle/ref_build/torch_compat.h) the modules above were compiled from, written by
+# oracle/ref_build/Makefile next to them; stored in every fixture as `ref_sources_sha256`
+_SRC_SHA = (ROOT / "oracle" / "_ref" / "SOURCES.sha256").read_text()
+_savez = np.savez_compressed
+
+
+def _savez_stamped(path, **arrays):
+    _savez(path, ref_sources_sha256=np.asarray(_SRC_SHA), **arrays)
+
+
+np.savez_compressed = _savez_stamped
 
 
 def t(a):

@@ -116,3 +116,28 @@ def test_acc64_yardstick_psroipool(path, oracle):
     _, H, W = g["fm"].shape
     want, mag = oracle.psroipool_bwd_acc64(g["gout"], g["rois"], H, W)
     oracle.assert_within_contract(g["gin"], want, mag, 1e-5 if g["fm"].dtype == np.float32 else 1e-12, "PSROIPool gradient")
+
+
+def test_fixtures_record_the_reference_sources_they_were_made_from():
+    """Every fixture carries the sha256 of the reference files (and of oracle/ref_build/torch_compat.h, the one adaptation)
+    that oracle/_ref was compiled from when it was generated.  All fixtures agree; where /root/reference is mounted (the
+    build container) the hashes are re-derived from the files as they lie there today."""
+    import hashlib
+    from pathlib import Path
+    from conftest import GOLDEN
+    files = sorted(GOLDEN.glob("*.npz"))
+    stamps = set()
+    for f in files:
+        g = load_golden(f)
+        assert "ref_sources_sha256" in g, f"{f.name} has no source stamp: regenerate with tests/golden/make_golden.py"
+        stamps.add(str(g["ref_sources_sha256"]))
+    assert len(stamps) == 1, "fixtures were generated from different source states"
+    listed = dict(reversed(line.split(None, 1)) for line in stamps.pop().strip().splitlines())
+    assert len(listed) == 9 and "oracle/ref_build/torch_compat.h" in listed and "ps_roipool/ps_roipool_cuda.cu" in listed
+    ref = Path("/root/reference/detect_to_track/models")
+    root = Path(__file__).resolve().parents[1]
+    for name, digest in listed.items():
+        name = name.strip()
+        path = root / name if name.startswith("oracle/") else ref / name
+        if path.exists():                                             # the reference is absent on the GPU box
+            assert hashlib.sha256(path.read_bytes()).hexdigest() == digest, f"{name} changed since the fixtures were made"

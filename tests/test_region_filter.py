@@ -1,0 +1,89 @@
+"""Region proposals on the device: d2t_region_filter_f32 against the numpy restatement of the host
+pipeline the reference runs between the RPN and the R-FCN heads (oracle/regions.py; trainer.py:178-190)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "oracle"))
+import regions as oracle_regions  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _anchors(h, w, rng):
+    """reference utils.py:114-163 (build_anchors) with the default areas / aspect ratios (cfg/default.yaml:13-14)."""
+    areas, ratios = [0.001, 0.004, 0.016, 0.064, 0.256], [0.5, 1.0, 2.0]
+    dims = np.array([[np.sqrt(a * r), a / np.sqrt(a * r)] for a in areas for r in ratios])
+    iv, jv = np.meshgrid(np.linspace(0, 1, h, endpoint=False) + 1 / h / 2, np.linspace(0, 1, w, endpoint=False) + 1 / w / 2, indexing="ij")
+    ij = np.broadcast_to(np.stack([iv, jv], -1)[:, :, None, :], (h, w, len(dims), 2))
+    hw = np.broadcast_to(dims[None, None], (h, w, len(dims), 2))
+    return np.concatenate([ij, hw], 3).reshape(-1, 4).astype(np.float32)
+
+
+def test_oracle_decode_and_nms_known_answers():
+    a = np.array([[0.5, 0.5, 0.2, 0.4]], np.float32)
+    np.testing.assert_allclose(oracle_regions.box_decode(a, np.array([[0.5, -0.25, 0.0, np.log(2.0)]], np.float32)),
+                               [[0.6, 0.4, 0.2, 0.8]], rtol=1e-6)
+    boxes = np.array([[0.5, 0.5, 0.2, 0.2], [0.5, 0.52, 0.2, 0.2], [0.1, 0.1, 0.1, 0.1], [0.5, 0.5, 0.2, 0.2]], np.float32)
+    confs = np.array([0.9, 0.8, 0.7, 0.2], np.float32)
+    keep, kb = oracle_regions.region_filter(confs, boxes, 0.3, 10, 0.5)
+    assert keep.tolist() == [0, 2] and kb.shape == (2, 4)              # 1 overlaps 0 (IoU 0.82), 3 is under the threshold
+    assert oracle_regions.region_filter(confs, boxes, 0.3, 1, 0.5)[0].tolist() == [0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(38, 75, 0.3, 3000, 0.5, 0.5), (38, 63, 0.3, 3000, 0.3, 0.5), (10, 12, 0.5, 64, 0.5, 0.5),
+                                  (38, 75, 0.0, 4096, 0.7, 0.5), (20, 20, 0.9, 300, 0.5, 0.2), (5, 5, 0.99, 16, 0.5, 0.5)], ids=str)
+def test_matches_numpy_pipeline(case):
+    from detect_to_track.models import _ext
+    h, w, thr, k, iou, spread = case
+    rng = np.random.default_rng(h * 1000 + w)
+    anchors = _anchors(h, w, rng)
+    A = len(anchors)
+    offsets = (rng.standard_normal((A, 4)) * spread * [0.5, 0.5, 0.3, 0.3]).astype(np.float32)
+    confs = rng.random(A).astype(np.float32)
+    confs[rng.integers(0, A, A // 50)] = confs[0]                      # ties across the top-k boundary
+    boxes_d, conf_d, idx_d, count = _ext.region_filter(*(torch.from_numpy(x).to(DEV) for x in (anchors, offsets, confs)), thr, k, iou)
+    n = int(count.item())
+    # decode: compared on its own (expf vs numpy's exp: 1 ulp); the filters are compared on the device's own boxes
+    want_boxes = oracle_regions.box_decode(anchors, offsets)
+    idx = idx_d.cpu().numpy()
+    assert (idx[:n] >= 0).all() and (idx[n:] == -1).all()
+    got_boxes = boxes_d.cpu().numpy()
+    np.testing.assert_allclose(got_boxes[:n], want_boxes[idx[:n]], rtol=2e-6, atol=1e-7)
+    assert not got_boxes[n:].any() and not conf_d.cpu().numpy()[n:].any()
+    all_boxes = want_boxes.copy()
+    all_boxes[idx[:n]] = got_boxes[:n]                                 # the device's values where it reported them
+    keep, _ = oracle_regions.region_filter(confs, all_boxes, thr, k, iou)
+    if not np.array_equal(keep, idx[:n]):                              # a box the device dropped may differ in its last bit: retry with
+        sel = np.nonzero(confs > np.float32(thr))[0]                   # the candidates' device values is not possible (not exported) --
+        order = sel[np.argsort(-confs[sel], kind="stable")][:k]        # so demand agreement only when every IoU decision has a margin
+        b = want_boxes[order]
+        margin = min((np.abs(oracle_regions.iou_one_to_many(b[i], b[i + 1:]) - iou).min() if i + 1 < len(b) else 1.0) for i in range(len(b)))
+        assert margin < 1e-6, "kept sets differ although no IoU sits at the threshold"
+    else:
+        np.testing.assert_array_equal(conf_d.cpu().numpy()[:n], confs[keep])
+        assert n == len(keep) and (np.diff(confs[keep]) <= 0).all()
+
+
+@pytest.mark.gpu
+def test_degenerate_inputs():
+    from detect_to_track.models import _ext
+    a = torch.tensor(_anchors(4, 4, None), device=DEV)
+    A = a.shape[0]
+    off = torch.zeros(A, 4, device=DEV)
+    # nothing above the threshold: count 0, all padding
+    b, c, i, n = _ext.region_filter(a, off, torch.full((A,), 0.1, device=DEV), 0.3, 32, 0.5)
+    assert int(n) == 0 and not b.any() and bool((i == -1).all())
+    # NaN confidences are filtered out; identical boxes collapse to the first one of each anchor shape
+    conf = torch.full((A,), 0.9, device=DEV)
+    conf[::3] = float("nan")
+    b, c, i, n = _ext.region_filter(a, off, conf, 0.3, 32, 0.5)
+    kept = i[: int(n)].cpu().numpy()
+    assert int(n) > 0 and (kept % 3 != 0).all() and (np.diff(kept) > 0).all()       # equal confidences: anchor order
+    with pytest.raises(RuntimeError):
+        _ext.region_filter(a, off, conf, 0.3, 5000, 0.5)                              # max_dets > 4096
