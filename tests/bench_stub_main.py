@@ -75,6 +75,7 @@ if __name__ == "__main__":
     a.no_cpu_baseline = True
     stub = CpuStub()
     bench.run(a, stub)
-    n = stub.n_sets + a.warmup + a.steps * (3 if a.graph else 1)   # graph mode: untimed replay + timed replay + eager event pass
+    settle = min(3 * a.steps, 60)                                  # bounded untimed steps before the timed region
+    n = stub.n_sets + a.warmup + settle + a.steps * (3 if a.graph else 1)   # + the timed steps (+ 2 graph replays of them)
     assert stub.calls == {"fwd": n, "bwd": n}, stub.calls
     print(f"stub rank {stub.rank} done", file=sys.stderr)
