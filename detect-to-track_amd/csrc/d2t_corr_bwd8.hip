@@ -133,11 +133,16 @@ typedef std::integral_constant<int, 5> I5;
 
 // The strip walk for one role (compile-time: the two roles differ in the ring write pattern and in which
 // k-block of a tile is structurally zero; a run-time role splits the pinned schedule into many basic blocks).
-template <int role, int S8_CT, bool ROWKB, int ABL = 0>    // ABL: ablation mask of csrc/lab/bwd8_stamp_lab (timing only)
+// FLEX: the workgroup owns the c-tiles [ct0, ct0 + nct) of its strip, nct <= 16, dealt to the waves round-robin (wave w:
+// c-tiles w and w + 8, so that the two waves of a SIMD carry ceil(nct / 4) between them); a wave's missing c-tile is
+// skipped behind wave-uniform branches.  That lets the host cut the channels of a SMALL grid (the model's B = 1 pairs:
+// 32-38 strips) into as many blocks as fill the chip once, instead of 256-channel blocks that fill 60 % of it (C = 1024)
+// or need a second, nearly empty round (C = 2048).  !FLEX: 256 channels, wave w = c-tiles 2w, 2w + 1, no branches.
+template <int role, int S8_CT, bool ROWKB, int ABL = 0, bool FLEX = false>    // ABL: ablation mask of csrc/lab/bwd8_stamp_lab (timing only)
 __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const float* __restrict__ gout,
                                             const float* __restrict__ fm0, const float* __restrict__ fm1,
                                             float* __restrict__ g0, float* __restrict__ g1,
-                                            int b, int tj, int C, int H, int W, int tiles_i)
+                                            int b, int tj, int C, int H, int W, int tiles_i, int ct0, int nct)
 {
     constexpr int S8_WAVES = 16 / S8_CT;
     constexpr int GT = S8_WAVES * 64, S8_NQ = 2048 / GT;             // threads, ring quads per thread
@@ -157,7 +162,8 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     const __amdgpu_buffer_rsrc_t rx = uniform_rsrc(gx, plane_bytes);
     const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(gb, (unsigned)HW * CELLS * 4u);
 
-    const int cw = blockIdx.y * S8_CH + wave * (S8_CT * 16);          // first channel of this wave's two c-tiles
+    const int cw = FLEX ? (ct0 + wave) * 16 : blockIdx.y * S8_CH + wave * (S8_CT * 16);   // first channel of this wave's first c-tile
+    const bool on[2] = {!FLEX || wave < nct, !FLEX || wave + S8_WAVES < nct};             // which of its c-tiles exist (wave-uniform)
     // S piece of k-block q at super-step 0, c-tile 0 (bytes): lane (channel n, slot group 4q+g).  Channels
     // >= C lie behind the buffer: zeros.  Rows >= H (last super-step) read the next plane: their G is 0.
     int sv[KB_SS];
@@ -167,7 +173,7 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
         kb_slot<ROWKB>(q, g, xr, cg);
         sv[q] = ((cw + n) * HW + xr * W + col0 + 4 * cg) * 4;
     }
-    const int s_step = 4 * W * 4, ct_step = 16 * HW * 4;
+    const int s_step = 4 * W * 4, ct_step = (FLEX ? S8_WAVES * 16 : 16) * HW * 4;
     auto s_load = [&](int ss, int q, int ct) -> f32x4 {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, sv[q] + ss * s_step + ct * ct_step, 0, 0);
         return __builtin_bit_cast(f32x4, v);
@@ -216,16 +222,18 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
         const int base = col_ok && i < H ? x_lane + 4 * u * W * 4 : S8_OOR;
         bool bad = false;
 #pragma unroll
-        for (int ct = 0; ct < S8_CT; ++ct) bad = bad || nonfinite4(d[ct]);
+        for (int ct = 0; ct < S8_CT; ++ct) bad = bad || (on[ct] && nonfinite4(d[ct]));
         badt |= bad && base != S8_OOR ? 1ull << (u & 63) : 0ull;
 #pragma unroll
-        for (int ct = 0; ct < S8_CT; ++ct)
+        for (int ct = 0; ct < S8_CT; ++ct) {
+            if (FLEX && !on[ct]) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = d[ct][r];                            // (a bit_cast of the element lvalue d[ct][r] reads element 0)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rx,
                                                       base == S8_OOR ? S8_OOR : base + ct * ct_step + r * HW * 4, 0, 0);
             }
+        }
     };
 
     f32x4 acc[S8_CT][NACT], a4[KB_SS][S8_CT], done[S8_CT];
@@ -242,7 +250,7 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
 #pragma unroll
     for (int q = 0; q < KB_SS; ++q)
 #pragma unroll
-        for (int ct = 0; ct < S8_CT; ++ct) a4[q][ct] = s_load(0, q, ct);
+        for (int ct = 0; ct < S8_CT; ++ct) a4[q][ct] = !FLEX || on[ct] ? s_load(0, q, ct) : f32x4{0.f, 0.f, 0.f, 0.f};
     g_put_all(ring[0]);
     g_load_all(1);
     lds_barrier();
@@ -269,12 +277,23 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
             // tile's window, for role 1 the one on the row above its newest tile's window.
             const int A0 = (role == 0 && q == DEAD0 && LO == 0) ? 1 : LO;
             const int A1 = (role == 1 && q == 0 && HI == NACT) ? NACT - 1 : HI;
+            if (!FLEX) {
 #pragma unroll
-            for (int s = s_lo; s < s_hi; ++s)
+                for (int s = s_lo; s < s_hi; ++s)
 #pragma unroll
-                for (int a = A0; a < A1; ++a)
+                    for (int a = A0; a < A1; ++a)
 #pragma unroll
-                    for (int ct = 0; ct < S8_CT; ++ct) acc[ct][a] = D2T_MFMA(a4[q][ct][s], bv[a][s], acc[ct][a]);
+                        for (int ct = 0; ct < S8_CT; ++ct) acc[ct][a] = D2T_MFMA(a4[q][ct][s], bv[a][s], acc[ct][a]);
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < S8_CT; ++ct) {
+                    if (!on[ct]) continue;                           // wave-uniform
+#pragma unroll
+                    for (int s = s_lo; s < s_hi; ++s)
+#pragma unroll
+                        for (int a = A0; a < A1; ++a) acc[ct][a] = D2T_MFMA(a4[q][ct][s], bv[a][s], acc[ct][a]);
+                }
+            }
         };
         auto kblock = [&](f32x4 (&bv)[NACT], f32x4 (&bvn)[NACT], auto q_c) {
             constexpr int q = decltype(q_c)::value;
@@ -284,20 +303,27 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
             D2T_PIN();
             mfma(bv, q, 1, 2);
             D2T_PIN();
-            if (q <= 2) D2T_WCLK(w_a);
-            if (q == 0) {                            // complete since the end of the previous super-step
-                if (!(ABL & 2)) store_tile(done, ss - 3);
-                else asm volatile("" ::"v"(done[0]), "v"(done[S8_CT - 1]));
-            }
-            if (q == 1 && !(ABL & 8)) g_put_all(ring[cur ^ 1]);      // G(ss+1), requested a super-step ago; that buffer was last read in ss-1
-            if (q == 2 && !(ABL & 4)) g_load_all(ss + 2);            // past the map: out of range, zeros
-            if (q <= 2) { D2T_WCLK(w_b); D2T_LAB_ONLY(w_sl[q <= 2 ? q : 0] += w_b - w_a;) }
+            // The super-step's non-MFMA work: tile store (k-block 0), ring writes of G(ss+1) (1), requests for G(ss+2) (2).
+            // (Measured and dropped: placing it behind the 40th MFMA for waves 4-7 so that the two waves of a SIMD never
+            // sit in it together -- no change, 72.1 us either way: the cost of these memory instructions is their wait
+            // for the texture-address unit, csrc/lab/ta_lab, not the coincidence.)
+            auto slice = [&]() {
+                if (q <= 2) D2T_WCLK(w_a);
+                if (q == 0) {                                        // complete since the end of the previous super-step
+                    if (!(ABL & 2)) store_tile(done, ss - 3);
+                    else asm volatile("" ::"v"(done[0]), "v"(done[S8_CT - 1]));
+                }
+                if (q == 1 && !(ABL & 8)) g_put_all(ring[cur ^ 1]);  // G(ss+1), requested a super-step ago; that buffer was last read in ss-1
+                if (q == 2 && !(ABL & 4)) g_load_all(ss + 2);        // past the map: out of range, zeros
+                if (q <= 2) { D2T_WCLK(w_b); D2T_LAB_ONLY(w_sl[q <= 2 ? q : 0] += w_b - w_a;) }
+            };
+            slice();
             D2T_PIN();
             mfma(bv, q, 2, 4);
             D2T_PIN();
 #pragma unroll
             for (int ct = 0; ct < S8_CT; ++ct)
-                if (!(ABL & 1)) a4[q][ct] = s_load(ss + 1, q, ct);   // a whole super-step ahead
+                if (!(ABL & 1) && (!FLEX || on[ct])) a4[q][ct] = s_load(ss + 1, q, ct);   // a whole super-step ahead
             if (q == KB_SS - 2) {
                 // every wave has issued (and, lgkmcnt(0), received) its last fragments of ring[cur] and written its
                 // part of ring[cur^1]: publish.  The k-block behind the barrier runs from registers.
@@ -376,29 +402,33 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
         for (int off = 32; off; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
         const unsigned long long m = ((unsigned long long)hi << 32) | lo;
         for (int ct = 0; ct < S8_CT; ++ct) {
+            if (FLEX && !on[ct]) continue;
             if (tiles_i > 64) {
-                strip_repair(role, lane, gb, S, gx, cw + 16 * ct, C, H, W, j0, CELLS, 1, 0, H);
+                strip_repair(role, lane, gb, S, gx, cw + (FLEX ? 16 * S8_WAVES : 16) * ct, C, H, W, j0, CELLS, 1, 0, H);
             } else {
                 for (int u = 0; u < tiles_i; ++u)
                     if ((m >> u) & 1)
-                        strip_repair(role, lane, gb, S, gx, cw + 16 * ct, C, H, W, j0, CELLS, 1, 4 * u, 4 * u + 4 < H ? 4 * u + 4 : H);
+                        strip_repair(role, lane, gb, S, gx, cw + (FLEX ? 16 * S8_WAVES : 16) * ct, C, H, W, j0, CELLS, 1, 4 * u, 4 * u + 4 < H ? 4 * u + 4 : H);
             }
         }
     }
 }
 #undef D2T_PIN
 
-template <int CT, bool ROWKB, int ABL = 0>
+template <int CT, bool ROWKB, int ABL = 0, bool FLEX = false>
 __global__ void __launch_bounds__(1024 / CT)
 k_corr_bwd_strip8(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
                   float* __restrict__ g0, float* __restrict__ g1,
                   int B, int C, int H, int W, int tiles_i, int tiles_j)
 {
+    const int Ct = (C + 15) / 16;                                    // FLEX: gridDim.y blocks of consecutive c-tiles, sizes differ by at most one
+    const int ct0 = FLEX ? (int)((long long)blockIdx.y * Ct / gridDim.y) : 0;
+    const int nct = FLEX ? (int)((long long)(blockIdx.y + 1) * Ct / gridDim.y) - ct0 : 16;
     __shared__ __attribute__((aligned(16))) float ring[2][S8_RING];  // 64 KB
     const int bid = xcd_remap(blockIdx.x, gridDim.x);                // both roles of a batch item stay on one XCD: they share gradOut[b]
     const int tj = bid % tiles_j, role = (bid / tiles_j) & 1, b = bid / (2 * tiles_j);
-    if (role) strip8_body<1, CT, ROWKB, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
-    else strip8_body<0, CT, ROWKB, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
+    if (role) strip8_body<1, CT, ROWKB, ABL, FLEX>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i, ct0, nct);
+    else strip8_body<0, CT, ROWKB, ABL, FLEX>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i, ct0, nct);
 }
 
 }  // namespace
@@ -424,15 +454,38 @@ void lab8_launch(const float* gout, const float* fm0, const float* fm1, float* g
 }
 #endif
 
+// How many channel blocks per strip?  Model of a workgroup's time: a fixed part (prologue, G production, tails) plus the
+// c-tiles of its busiest SIMD; of the launch: that, times the rounds of workgroups (one per CU).  Measured anchor: the
+// metric shape, 16 c-tiles per workgroup (4 per SIMD) = 72 us.
+int corr_bwd8_blocks(int B, int C, int W)
+{
+    const int Ct = (C + 15) / 16, strips = 2 * B * ((W + TP - 1) / TP);
+    int best = (Ct + 15) / 16;
+    double best_t = 1e30;
+    for (int nb = (Ct + 15) / 16; nb <= Ct && nb <= 64; ++nb) {
+        const int n = (Ct + nb - 1) / nb, per_simd = (n + 3) / 4;
+        const long long wgs = 1LL * strips * nb;
+        const double t = (double)((wgs + 255) / 256) * (12.0 + 15.0 * per_simd);
+        if (t < best_t - 1e-9) { best_t = t; best = nb; }
+    }
+    return best;
+}
+
 int corr_bwd8_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
                   int B, int C, int H, int W, hipStream_t st, int variant)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
-    const dim3 grid(2 * B * tiles_j, (C + S8_CH - 1) / S8_CH);
-if (variant == 1)                                                // the row-major k-block enumeration (A/B measurements)
-        hipLaunchKernelGGL((k_corr_bwd_strip8<2, false>), grid, dim3(512), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
-    else
-        hipLaunchKernelGGL((k_corr_bwd_strip8<2, true>), grid, dim3(512), 0, st, gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    const int nb = corr_bwd8_blocks(B, C, W);
+    if (variant == 1) {                                              // the row-major k-block enumeration (A/B measurements)
+        hipLaunchKernelGGL((k_corr_bwd_strip8<2, false>), dim3(2 * B * tiles_j, (C + S8_CH - 1) / S8_CH), dim3(512), 0, st,
+                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    } else if (C % S8_CH == 0 && nb == C / S8_CH) {                   // whole 256-channel blocks (the metric shape): no branches
+        hipLaunchKernelGGL((k_corr_bwd_strip8<2, true>), dim3(2 * B * tiles_j, nb), dim3(512), 0, st,
+                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    } else {
+        hipLaunchKernelGGL((k_corr_bwd_strip8<2, true, 0, true>), dim3(2 * B * tiles_j, nb), dim3(512), 0, st,
+                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+    }
     return launch_status();
 }
 

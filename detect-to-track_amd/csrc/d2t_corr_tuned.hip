@@ -1367,9 +1367,10 @@ bool corr_bwd_supported(int B, int C, int H, int W, int d, int s)
 
 size_t corr_bwd_ws_bytes(int, int, int, int, int, int) { return 0; }
 
-// nl problems of one spatial shape.  A level whose 256-channel grid fills at least 100 CUs is launched by
-// itself (the 8-wave kernel of d2t_corr_bwd8.hip; k_corr_bwd_strip for the channel-major layout, short maps
-// or on request); the remaining levels share ONE launch of the 4-wave kernel, heaviest first.
+// nl problems of one spatial shape.  Reference layout: every level is launched by itself with the 8-wave kernel of
+// d2t_corr_bwd8.hip (channel blocks sized to the grid).  Channel-major layout, maps shorter than 17 rows, or on request:
+// a level whose 256-channel grid fills at least 100 CUs takes k_corr_bwd_strip, the remaining levels share ONE launch
+// of the 4-wave kernel, heaviest first.
 int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
                         float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
                         int bwd_variant)
@@ -1378,8 +1379,8 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
     int small[MAXLV], ns = 0;
     for (int l = 0; l < nl; ++l) {
         const long long wide = 2LL * B * tiles_j * ((C[l] + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
-        if (wide >= 100 && bwd_variant != 1 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {
-            const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st, bwd_variant == 2);
+        if (bwd_variant != 1 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {   // any grid: the kernel cuts the channels to fit it
+            const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st, bwd_variant == 2 ? 1 : 0);
             if (rc != D2T_OK) return rc;
         } else if (wide >= 100 && lay.cs == 1)
             hipLaunchKernelGGL(k_corr_bwd_strip<true>, dim3(2 * B * tiles_j, (C[l] + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,

@@ -12,7 +12,7 @@ for shape in [(3, 20, 38, 75), (2, 300, 21, 44), (8, 256, 38, 63)]:
     gout = torch.randn(B, H, W, 17, 17, generator=g).to(dev)
     r0, r1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, 1)
     scale = float(r0.abs().max())
-    for impl in (0, 3, 4, 5, 6):
+    for impl in (0, 3, 4):
         g0, g1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, impl)
         e0, e1 = float((g0 - r0).abs().max()) / scale, float((g1 - r1).abs().max()) / scale
         h0, h1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, impl)
