@@ -161,7 +161,10 @@ def test_module_matches_reference_composition():
     gb = [ins_b["p0"][k].grad for k in ("c3", "c4", "c5")] + [ins_b["p1"][k].grad for k in ("c3", "c4", "c5")] + \
          [ins_b["r0"].grad, ins_b["r1"].grad, mod.reg_fc.weight.grad.clone()]
     for x, y in zip(ga, gb):
-        assert x is not None and torch.equal(x, y)
+        # the fused backward reads the channel-major gradient in place (16- / 4-wave strip kernels), the composition calls
+        # PointwiseCorrelation's backward on the reference layout (8-wave kernel): same terms, other summation order
+        assert x is not None
+        torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-5 * float(y.abs().max()))
 
 
 def test_levels_argument_errors():
