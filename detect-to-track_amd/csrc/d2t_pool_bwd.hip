@@ -697,7 +697,11 @@ k_psroipool_bwd_plane_lds(const float* __restrict__ gout, const float* __restric
     float* mine = planes + wave * HW;
     for (int e = lane; e < HW; e += 64) mine[e] = 0.f;
     const int dy = lane >> 3, dx = lane & 7, loff = dy * W + dx;
-    const int r_lo = (int)((long long)R * wave / PL_WAVES), r_hi = (int)((long long)R * (wave + 1) / PL_WAVES);
+    // gridDim.y workgroups share a plane (few planes, many RoIs: 196 workgroups of 3000 RoIs each leave a quarter of the
+    // chip idle and the rest latency-bound): RoI slice blockIdx.y, then a quarter of it per wave; every slice writes its
+    // own partial plane and k_psroipool_bwd_gather adds the slices in ascending order
+    const int part_id = blockIdx.y * PL_WAVES + wave, parts = gridDim.y * PL_WAVES;
+    const int r_lo = (int)((long long)R * part_id / parts), r_hi = (int)((long long)R * (part_id + 1) / parts);
     const int bi = bin / KT, bj = bin - bi * KT;
     const float* gp = gout + plane;
     for (int rb = r_lo; rb < r_hi; rb += 64) {
@@ -745,7 +749,7 @@ k_psroipool_bwd_plane_lds(const float* __restrict__ gout, const float* __restric
         }
     }
     __syncthreads();
-    float* dst = part + (size_t)plane * HW;
+    float* dst = part + ((size_t)blockIdx.y * gridDim.x + plane) * HW;
     for (int e = threadIdx.x; e < HW; e += PL_WAVES * 64)
         dst[e] = ((planes[e] + planes[HW + e]) + planes[2 * HW + e]) + planes[3 * HW + e];
 }
@@ -757,7 +761,7 @@ k_psroipool_bwd_plane_lds(const float* __restrict__ gout, const float* __restric
 // phase 2: gin[ch] = sum of the planes that map to ch, ascending bin then t; channels nothing
 // maps to are zero.
 __global__ void __launch_bounds__(256)
-k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, int nT, int HW)
+k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, int nT, int HW, int nslice = 1)
 {
     // planes (t, bin) with (t+1)*bin == ch, ascending bin: lane b-1 of the first wave tests bin b
     __shared__ int32_t srcs[KK];
@@ -772,12 +776,15 @@ k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, 
     }
     __syncthreads();
     const int ns = nsrc;
+    const size_t slice = (size_t)nT * KK * HW;                       // partial planes of one RoI slice (nslice = 1: the planes themselves)
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
         float a = 0.f;
         if (ch == 0) {                                               // bin 0 of every target
-            for (int t = 0; t < nT; ++t) a += part[(size_t)(t * KK) * HW + p];
+            for (int t = 0; t < nT; ++t)
+                for (int sl = 0; sl < nslice; ++sl) a += part[sl * slice + (size_t)(t * KK) * HW + p];
         } else {
-            for (int k = 0; k < ns; ++k) a += part[(size_t)srcs[k] * HW + p];
+            for (int k = 0; k < ns; ++k)
+                for (int sl = 0; sl < nslice; ++sl) a += part[sl * slice + (size_t)srcs[k] * HW + p];
         }
         gin[(size_t)ch * HW + p] = a;
     }
@@ -788,10 +795,20 @@ static bool psroipool_bwd_planes_supported(int R, int nT, int H, int W, int k)
     return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && H <= 4 * PX_MAXROWS && W <= 64 * PX_XG && nT * KK <= 65535;
 }
 
+// RoI slices per plane of the LDS form: enough workgroups for ~3 per CU, at least ~128 RoIs per slice
+static int ps_plane_slices(int R, int nT, int H, int W)
+{
+    if (H * W > PL_MAXPIX || nT * KK >= 512) return 1;
+    int s = (768 + nT * KK - 1) / (nT * KK);
+    const int by_rois = R / 128 > 1 ? R / 128 : 1;
+    s = s > by_rois ? by_rois : s;
+    return s > 8 ? 8 : s;
+}
+
 static size_t psroipool_bwd_planes_ws_bytes(int R, int nT, int H, int W, int k)
 {
     if (!psroipool_bwd_planes_supported(R, nT, H, W, k)) return 0;
-    return bins_bytes(R) + align256((size_t)nT * KK * H * W * sizeof(float));
+    return bins_bytes(R) + align256((size_t)ps_plane_slices(R, nT, H, W) * nT * KK * H * W * sizeof(float));
 }
 
 static int psroipool_bwd_planes_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
@@ -800,14 +817,15 @@ static int psroipool_bwd_planes_f32(const float* gout, const float* rois, float*
     int32_t* cells = static_cast<int32_t*>(ws);                      // only the register-band form reads a cell table
     float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + bins_bytes(R));
     int rc;
+    const int nslice = ps_plane_slices(R, nT, H, W);
     if (H * W <= PL_MAXPIX) {
         // few planes (< 2 workgroups per CU): one wave per SIMD, latency-bound -> sweep 64 cells at a time;
         // many planes: the LDS float-add rate (~3.4 cycles per lane) would bound -> per-cell read-add-write
-        if (nT * KK < 512)
-            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<true>, dim3(nT * KK), dim3(PL_WAVES * 64),
+        if (nT * KK < 512 && nslice == 1)
+            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<true>, dim3(nT * KK, nslice), dim3(PL_WAVES * 64),
                                (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
         else
-            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<false>, dim3(nT * KK), dim3(PL_WAVES * 64),
+            hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<false>, dim3(nT * KK, nslice), dim3(PL_WAVES * 64),
                                (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
     } else {
         rc = psroipool_bins<float>(rois, cells, R, H, W, k, st);
@@ -820,7 +838,7 @@ static int psroipool_bwd_planes_f32(const float* gout, const float* rois, float*
     rc = launch_status();
     if (rc != D2T_OK) return rc;
     const int HW = H * W;
-    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW, nslice);
     return launch_status();
 }
 

@@ -365,7 +365,7 @@ int ps_cells_T(const float* rois, int4* cellsT, int R, int H, int W, hipStream_t
 // reference's running sum over its cell in row-major order and its guarded IEEE divide:
 // bit-identical.  tmpT[(t*49+bin)][r] is transposed to out[r][t][bin] by the caller.
 // ---------------------------------------------------------------------------------------
-constexpr int PF_RC = 1024;                   // RoIs per workgroup
+constexpr int PF_RC = 1024;                   // RoIs per workgroup (4096 -- the map staged once per channel at R = 3000 -- measured 2.2x SLOWER: channels that feed many planes become stragglers)
 
 __global__ void __launch_bounds__(256)
 k_psroipool_fwd_chan(const float* __restrict__ fm, const int4* __restrict__ cellsT, float* __restrict__ tmpT,
