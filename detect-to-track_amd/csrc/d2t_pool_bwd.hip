@@ -795,15 +795,10 @@ static bool psroipool_bwd_planes_supported(int R, int nT, int H, int W, int k)
     return k == KT && R >= 1 && nT >= 1 && H >= 1 && W >= 1 && H <= 4 * PX_MAXROWS && W <= 64 * PX_XG && nT * KK <= 65535;
 }
 
-// RoI slices per plane of the LDS form: enough workgroups for ~3 per CU, at least ~128 RoIs per slice
-static int ps_plane_slices(int R, int nT, int H, int W)
-{
-    if (H * W > PL_MAXPIX || nT * KK >= 512) return 1;
-    int s = (768 + nT * KK - 1) / (nT * KK);
-    const int by_rois = R / 128 > 1 ? R / 128 : 1;
-    s = s > by_rois ? by_rois : s;
-    return s > 8 ? 8 : s;
-}
+// RoI slices per plane of the LDS form.  Measured in round 3 at R = 3000, nT = 4 (196 planes): 4 slices per plane (784
+// workgroups instead of 196) leave k_psroipool_bwd_plane_lds<true> at 53.6 us (1 slice: 54-56) and the per-cell form at
+// 65 us -- the kernel is not short of workgroups, its LDS read-add-write chain per cell is what takes the time.  So: 1.
+static int ps_plane_slices(int, int, int, int) { return 1; }
 
 static size_t psroipool_bwd_planes_ws_bytes(int R, int nT, int H, int W, int k)
 {
@@ -821,7 +816,7 @@ static int psroipool_bwd_planes_f32(const float* gout, const float* rois, float*
     if (H * W <= PL_MAXPIX) {
         // few planes (< 2 workgroups per CU): one wave per SIMD, latency-bound -> sweep 64 cells at a time;
         // many planes: the LDS float-add rate (~3.4 cycles per lane) would bound -> per-cell read-add-write
-        if (nT * KK < 512 && nslice == 1)
+        if (nT * KK < 512)
             hipLaunchKernelGGL(k_psroipool_bwd_plane_lds<true>, dim3(nT * KK, nslice), dim3(PL_WAVES * 64),
                                (size_t)PL_WAVES * H * W * sizeof(float), st, gout, rois, part, R, nT, H, W);
         else
