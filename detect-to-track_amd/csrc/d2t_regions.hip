@@ -52,8 +52,8 @@ k_region_decode(const float* __restrict__ anchors, const float* __restrict__ off
 // (confidence descending, anchor index ascending) with a bitonic network in LDS, gather their boxes.
 __global__ void __launch_bounds__(RG_T)
 k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes, const float* __restrict__ confs,
-              float* __restrict__ sboxes, float* __restrict__ sconf, int* __restrict__ sidx, int* __restrict__ nsel, int A, int K)
-{
+              float* __restrict__ sboxes, float* __restrict__ sconf, int* __restrict__ sidx, int* __restrict__ nsel, int A, int K, int NS)
+{   // NS: the sorting network's size, the power of two >= K (<= RG_MAXK)
     __shared__ unsigned hist[256];
     __shared__ unsigned long long cand[RG_MAXK];
     __shared__ unsigned scan[RG_T];
@@ -132,12 +132,12 @@ k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes
     }
     const int n = (int)(tot < (unsigned)K ? tot : (unsigned)K);
     __syncthreads();
-    for (int e = n + tid; e < RG_MAXK; e += RG_T) cand[e] = 0ull;    // padding sorts to the end
+    for (int e = n + tid; e < NS; e += RG_T) cand[e] = 0ull;         // padding sorts to the end
     __syncthreads();
     // ---- bitonic sort, descending
-    for (int k2 = 2; k2 <= RG_MAXK; k2 <<= 1)
+    for (int k2 = 2; k2 <= NS; k2 <<= 1)
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int e = tid; e < RG_MAXK; e += RG_T) {
+            for (int e = tid; e < NS; e += RG_T) {
                 const int p = e ^ j;
                 if (p > e) {
                     const unsigned long long x = cand[e], y = cand[p];
@@ -261,7 +261,9 @@ int region_filter_f32(const float* anchors, const float* offsets, const float* c
     int* nsel = reinterpret_cast<int*>(w); w += 256;
     unsigned long long* mask = reinterpret_cast<unsigned long long*>(w);
     hipLaunchKernelGGL(k_region_decode, dim3((A + 255) / 256), dim3(256), 0, st, anchors, offsets, confs, boxes, keys, A, conf_thresh);
-    hipLaunchKernelGGL(k_region_topk, dim3(1), dim3(RG_T), 0, st, keys, boxes, confs, sboxes, sconf, sidx, nsel, A, max_dets);
+    int ns = 64;
+    while (ns < max_dets) ns <<= 1;
+    hipLaunchKernelGGL(k_region_topk, dim3(1), dim3(RG_T), 0, st, keys, boxes, confs, sboxes, sconf, sidx, nsel, A, max_dets, ns);
     const int nb = (max_dets + 63) / 64;
     hipLaunchKernelGGL(k_region_mask, dim3(nb, nb), dim3(64), 0, st, sboxes, nsel, mask, iou_thresh);
     hipLaunchKernelGGL(k_region_nms, dim3(1), dim3(64), 0, st, sboxes, sconf, sidx, nsel, mask, out_boxes, out_conf, out_idx, out_count, max_dets);
