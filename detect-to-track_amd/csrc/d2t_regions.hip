@@ -22,6 +22,7 @@ namespace {
 constexpr int RG_MAXK = 4096;                 // most boxes that can survive the max-det filter
 constexpr int RG_T = 1024;                    // threads of the single-workgroup kernels
 constexpr int RG_W = RG_MAXK / 64;            // 64-bit words per NMS mask row
+constexpr int RG_FUSE = 512;                  // most boxes the single-kernel path (top-k + IoU matrix + greedy scan) takes
 
 // monotone map float -> unsigned (larger float = larger key); 0 is reserved for "filtered out"
 __device__ __forceinline__ unsigned order_key(float f)
@@ -36,7 +37,10 @@ k_region_decode(const float* __restrict__ anchors, const float* __restrict__ off
                 float* __restrict__ boxes, unsigned* __restrict__ keys, int A, float thresh)
 {
     const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= A) return;
+    if (a >= A) {
+        if (a < ((A + 3) & ~3)) keys[a] = 0u;                        // the selection reads keys 16 bytes at a time
+        return;
+    }
     const float4 an = reinterpret_cast<const float4*>(anchors)[a], t = reinterpret_cast<const float4*>(offsets)[a];
     float4 b;
     b.x = t.x * an.z + an.x;
@@ -48,112 +52,257 @@ k_region_decode(const float* __restrict__ anchors, const float* __restrict__ off
     keys[a] = c > thresh ? order_key(c) : 0u;                        // NaN confidences are filtered out
 }
 
-// One workgroup: radix-select the max_dets-th largest key, compact the survivors in anchor order, sort them by
-// (confidence descending, anchor index ascending) with a bitonic network in LDS, gather their boxes.
+// ---- helpers of the single-workgroup kernel
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+// exclusive scan of v over the workgroup's RG_T threads (2 barriers); wtot: RG_T/64 words of LDS
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned& total, unsigned* wtot, int lane, int wave)
+{
+    const unsigned incl = wave_inclusive_scan(v, lane);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < RG_T / 64; ++w) {
+        const unsigned t = wtot[w];
+        base += w < wave ? t : 0u;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
+__device__ __forceinline__ float box_iou(const float4& a, const float4& b);
+
+// One workgroup does everything behind the decode: radix-select the max_dets-th largest key, compact the survivors,
+// order them by (confidence descending, anchor index ascending), gather their boxes and -- when max_dets <= RG_FUSE
+// -- the IoU bit matrix and the greedy scan as well (FUSED), so a frame's proposals cost two launches.
+//
+// NV > 0: the thread keeps 4*NV keys in registers (ONE round of coalesced 16-byte loads for the whole selection;
+// the first version re-read the keys from memory in each of the four passes, 35 dependent load latencies per pass
+// for a 38 x 63 map, and was 0.26 ms).  NV == 0: any A, keys re-read per pass.
+// The 256-bin histogram of a pass is built with one leader per wave-instruction taking the count of all lanes that
+// share its bin (confidences share their exponent: in the first passes almost every key falls into one bin and
+// plain LDS atomics would serialise), the rest adding themselves; the bin holding the K-th key is found with a scan.
+template <int NV, bool FUSED>
 __global__ void __launch_bounds__(RG_T)
 k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes, const float* __restrict__ confs,
-              float* __restrict__ sboxes, float* __restrict__ sconf, int* __restrict__ sidx, int* __restrict__ nsel, int A, int K, int NS)
-{   // NS: the sorting network's size, the power of two >= K (<= RG_MAXK)
+              float* __restrict__ sboxes, float* __restrict__ sconf, int* __restrict__ sidx, int* __restrict__ nsel,
+              float* __restrict__ out_boxes, float* __restrict__ out_conf, int* __restrict__ out_idx, int* __restrict__ out_count,
+              int A, int K, int NS, float iou)
+{   // NS: the sorting network's size, the power of two >= K (<= RG_MAXK); keys is padded with zeros to a multiple of 4
     __shared__ unsigned hist[256];
-    __shared__ unsigned long long cand[RG_MAXK];
-    __shared__ unsigned scan[RG_T];
-    __shared__ unsigned s_prefix, s_need, s_total;
-    const int tid = threadIdx.x;
+    __shared__ unsigned long long cand[RG_MAXK];                     // candidates; later the fused path's bit matrix
+    __shared__ unsigned wtot[RG_T / 64];
+    __shared__ unsigned s_prefix[4], s_need[4], s_eq[4], s_found[4];
+    __shared__ float4 sb[FUSED ? RG_FUSE : 1];
+    __shared__ float sc[FUSED ? RG_FUSE : 1];
+    __shared__ int si[FUSED ? RG_FUSE : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A4 = (A + 3) >> 2;                                     // 16-byte pieces of the key array
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 kv[NV > 0 ? NV : 1];
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = i * RG_T + tid;
+            kv[i] = q < A4 ? reinterpret_cast<const u32x4*>(keys)[q] : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // f(key, anchor index) over this thread's keys
+    auto for_each_key = [&](auto f) {
+        if constexpr (NV > 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const u32x4 v = kv[i];
+                const int a = (i * RG_T + tid) * 4;
+                f(v.x, a); f(v.y, a + 1); f(v.z, a + 2); f(v.w, a + 3);
+            }
+        } else {
+            for (int q = tid; q < A4; q += RG_T) {
+                const u32x4 v = reinterpret_cast<const u32x4*>(keys)[q];
+                f(v.x, 4 * q); f(v.y, 4 * q + 1); f(v.z, 4 * q + 2); f(v.w, 4 * q + 3);
+            }
+        }
+    };
+    if (tid < 4) s_found[tid] = 0;
 
     // ---- 4 passes of 8 bits, most significant first: `prefix` = the bits of the K-th largest key found so far
-    unsigned prefix = 0, need = (unsigned)K;                          // need: rank still wanted among keys matching the prefix
+    unsigned prefix = 0, need = (unsigned)K, eq = 0;                  // need: rank still wanted among the keys matching the prefix
+    bool found = true;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const unsigned hi_mask = pass == 0 ? 0u : 0xffffffffu << (shift + 8);
-        for (int a = tid; a < A; a += RG_T) {
-            const unsigned k = keys[a];
-            if (k != 0 && (k & hi_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {                                              // walk the 256 bins from the top
-            unsigned acc = 0, bin = 0, nd = need;
-            bool found = false;
-            for (int v = 255; v >= 0; --v) {
-                if (acc + hist[v] >= nd) { bin = (unsigned)v; nd -= acc; found = true; break; }
-                acc += hist[v];
+        for_each_key([&](unsigned k, int) {
+            const bool valid = k != 0 && (k & hi_mask) == prefix;
+            const unsigned long long live = __ballot(valid);
+            if (live) {                                              // wave-uniform
+                const unsigned bin = (k >> shift) & 255u;
+                const int lead = __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1);
+                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, lead);
+                const bool same = valid && bin == b;
+                const unsigned long long m = __ballot(same);
+                if (lane == lead) atomicAdd(&hist[b], (unsigned)__popcll(m));
+                if (valid && !same) atomicAdd(&hist[bin], 1u);
             }
-            if (!found) { bin = 0; nd = 0; }                         // fewer than K valid keys: everything valid is taken
-            s_prefix = prefix | (bin << shift);
-            s_need = found ? nd : 0;
-            s_total = found ? 1u : 0u;
+        });
+        __syncthreads();
+        const unsigned cnt = tid < 256 ? hist[255 - tid] : 0u;        // bins from the top
+        unsigned total;
+        const unsigned before = block_exclusive_scan(cnt, total, wtot, lane, wave);
+        if (tid < 256 && before < need && before + cnt >= need) {    // exactly one thread, or none when total < need
+            s_prefix[pass] = prefix | ((unsigned)(255 - tid) << shift);
+            s_need[pass] = need - before;
+            s_eq[pass] = cnt;
+            s_found[pass] = 1u;
         }
         __syncthreads();
-        prefix = s_prefix; need = s_need;
-        if (!s_total) { prefix = 0; need = 0; break; }               // (uniform: s_total is shared)
-        __syncthreads();
+        if (!s_found[pass]) { found = false; break; }                // fewer than K valid keys: everything valid is taken
+        prefix = s_prefix[pass]; need = s_need[pass]; eq = s_eq[pass];
     }
-    __syncthreads();
-    // survivors: key > T, plus the first `need` keys == T in anchor order (T = 0: all valid keys)
-    const unsigned T = prefix;
-    const int per = (A + RG_T - 1) / RG_T, a0 = tid * per, a1 = a0 + per < A ? a0 + per : A;
-    unsigned n_gt = 0, n_eq = 0;
-    for (int a = a0; a < a1; ++a) {
-        const unsigned k = keys[a];
-        n_gt += (k != 0 && k > T) ? 1u : 0u;
-        n_eq += (k != 0 && k == T && T != 0) ? 1u : 0u;
-    }
-    auto exclusive_scan = [&](unsigned v, unsigned& total) {         // over the 1024 threads
-        scan[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < RG_T; off <<= 1) {
-            const unsigned add = tid >= off ? scan[tid - off] : 0u;
-            __syncthreads();
-            scan[tid] += add;
-            __syncthreads();
-        }
-        total = scan[RG_T - 1];
-        const unsigned ex = scan[tid] - v;
-        __syncthreads();
-        return ex;
-    };
-    unsigned tot_gt, tot_eq;
-    const unsigned eq_before = exclusive_scan(n_eq, tot_eq);
-    unsigned take_eq = 0;                                            // how many of this thread's ties are taken
-    if (T != 0) {
-        const unsigned room = eq_before < need ? need - eq_before : 0u;
-        take_eq = n_eq < room ? n_eq : room;
-    }
+    // survivors: key > T, plus the first `need` keys == T in anchor order (not found: all valid keys)
+    const unsigned T = found ? prefix : 0u;
     unsigned tot;
-    const unsigned base = exclusive_scan(n_gt + take_eq, tot);
-    (void)tot_gt;
-    unsigned w = base, eq_left = take_eq;
-    for (int a = a0; a < a1; ++a) {
-        const unsigned k = keys[a];
-        bool take = k != 0 && k > T;
-        if (k != 0 && k == T && T != 0 && eq_left) { take = true; --eq_left; }
-        if (take && w < (unsigned)RG_MAXK) cand[w++] = ((unsigned long long)k << 32) | (unsigned)(0x7fffffff - a);   // ties: lower index = larger
+    if (NV > 0 && (!found || eq == need)) {
+        // every key equal to T is taken (the usual case: T is the K-th key itself): no order among the ties needed
+        unsigned cnt = 0;
+        for_each_key([&](unsigned k, int) { cnt += (k != 0 && k >= T) ? 1u : 0u; });
+        unsigned w = block_exclusive_scan(cnt, tot, wtot, lane, wave);
+        for_each_key([&](unsigned k, int a) {
+            if (k != 0 && k >= T && w < (unsigned)RG_MAXK) cand[w++] = ((unsigned long long)k << 32) | (unsigned)(0x7fffffff - a);
+        });
+    } else {
+        // ties cut by the K-th rank: walk the anchors in order (threads own contiguous ranges; keys re-read)
+        const int per = (A + RG_T - 1) / RG_T, a0 = tid * per, a1 = a0 + per < A ? a0 + per : A;
+        unsigned n_gt = 0, n_eq = 0;
+        for (int a = a0; a < a1; ++a) {
+            const unsigned k = keys[a];
+            n_gt += (k != 0 && k > T) ? 1u : 0u;
+            n_eq += (k != 0 && k == T && T != 0) ? 1u : 0u;
+        }
+        unsigned tot_eq;
+        const unsigned eq_before = block_exclusive_scan(n_eq, tot_eq, wtot, lane, wave);
+        unsigned take_eq = 0;                                        // how many of this thread's ties are taken
+        if (T != 0) {
+            const unsigned room = eq_before < need ? need - eq_before : 0u;
+            take_eq = n_eq < room ? n_eq : room;
+        }
+        unsigned w = block_exclusive_scan(n_gt + take_eq, tot, wtot, lane, wave), eq_left = take_eq;
+        for (int a = a0; a < a1; ++a) {
+            const unsigned k = keys[a];
+            bool take = k != 0 && k > T;
+            if (k != 0 && k == T && T != 0 && eq_left) { take = true; --eq_left; }
+            if (take && w < (unsigned)RG_MAXK) cand[w++] = ((unsigned long long)k << 32) | (unsigned)(0x7fffffff - a);   // ties: lower index = larger
+        }
     }
     const int n = (int)(tot < (unsigned)K ? tot : (unsigned)K);
     __syncthreads();
-    for (int e = n + tid; e < NS; e += RG_T) cand[e] = 0ull;         // padding sorts to the end
-    __syncthreads();
-    // ---- bitonic sort, descending
-    for (int k2 = 2; k2 <= NS; k2 <<= 1)
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int e = tid; e < NS; e += RG_T) {
-                const int p = e ^ j;
-                if (p > e) {
-                    const unsigned long long x = cand[e], y = cand[p];
-                    const bool desc = (e & k2) == 0;
-                    if (desc ? x < y : x > y) { cand[e] = y; cand[p] = x; }
+
+    // ---- order: (key descending, anchor ascending).  Up to 1024 candidates: every thread ranks its own among all
+    // (the composite values are distinct; LDS broadcast reads, no barrier); more: bitonic network.
+    auto emit = [&](int pos, unsigned long long c) {
+        const int a = 0x7fffffff - (int)(unsigned)(c & 0xffffffffu);
+        const float4 bx = reinterpret_cast<const float4*>(boxes)[a];
+        const float cf = confs[a];
+        if constexpr (FUSED) { sb[pos] = bx; sc[pos] = cf; si[pos] = a; }
+        else { reinterpret_cast<float4*>(sboxes)[pos] = bx; sconf[pos] = cf; sidx[pos] = a; }
+    };
+    if (n <= RG_T) {
+        if (tid < n) {
+            const unsigned long long x = cand[tid];
+            int rank = 0;
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) rank += cand[j] > x ? 1 : 0;
+            emit(rank, x);
+        }
+    } else {
+        for (int e = n + tid; e < NS; e += RG_T) cand[e] = 0ull;     // padding sorts to the end
+        __syncthreads();
+        for (int k2 = 2; k2 <= NS; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int e = tid; e < NS; e += RG_T) {
+                    const int p = e ^ j;
+                    if (p > e) {
+                        const unsigned long long x = cand[e], y = cand[p];
+                        const bool desc = (e & k2) == 0;
+                        if (desc ? x < y : x > y) { cand[e] = y; cand[p] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int e = tid; e < n; e += RG_T) emit(e, cand[e]);
+    }
+    if constexpr (!FUSED) {
+        if (tid == 0) *nsel = n;
+        return;
+    } else {
+        // ---- fused tail (n <= RG_FUSE): bit matrix in LDS (over cand, which is dead), greedy scan by wave 0
+        __syncthreads();
+        constexpr int FW = RG_FUSE / 64;
+        unsigned long long (*msk)[FW] = reinterpret_cast<unsigned long long (*)[FW]>(cand);
+        const int nw = (n + 63) >> 6;
+        for (int item = tid; item < n * nw; item += RG_T) {
+            const int i = item / nw, w = item - i * nw;
+            unsigned long long m = 0;
+            if (w >= (i >> 6)) {
+                const float4 me = sb[i];
+                for (int j = 0; j < 64; ++j) {
+                    const int c = 64 * w + j;
+                    if (c > i && c < n && box_iou(me, sb[c]) > iou) m |= 1ull << j;
                 }
             }
-            __syncthreads();
+            msk[i][w] = m;
         }
-    for (int e = tid; e < n; e += RG_T) {
-        const int a = 0x7fffffff - (int)(unsigned)(cand[e] & 0xffffffffu);
-        reinterpret_cast<float4*>(sboxes)[e] = reinterpret_cast<const float4*>(boxes)[a];
-        sconf[e] = confs[a];
-        sidx[e] = a;
+        __syncthreads();
+        if (wave != 0) return;
+        unsigned long long removed = 0;                              // word `lane` of the removed set
+        int kept = 0;
+        for (int blk = 0; blk < nw; ++blk) {
+            const int nb = n - 64 * blk < 64 ? n - 64 * blk : 64;
+            const unsigned long long diag = lane < nb ? msk[64 * blk + lane][blk] : 0ull;   // lane r: row r's own-block word
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            unsigned long long rem = __shfl(removed, blk, 64), keep = 0;
+            for (int r = 0; r < nb; ++r) {
+                const unsigned long long d = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, r) |
+                                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, r) << 32);
+                if (!((rem >> r) & 1)) { keep |= 1ull << r; rem |= d; }
+            }
+            if (lane > blk && lane < nw) {
+                unsigned long long acc = removed;
+                for (int r = 0; r < nb; ++r)
+                    if ((keep >> r) & 1) acc |= msk[64 * blk + r][lane];
+                removed = acc;
+            }
+            if (lane == blk) removed = rem;
+            const bool mine = lane < nb && ((keep >> lane) & 1);
+            const int pos = kept + __popcll(keep & ((1ull << lane) - 1ull));
+            if (mine && pos < K) {
+                const int src = 64 * blk + lane;
+                reinterpret_cast<float4*>(out_boxes)[pos] = sb[src];
+                out_conf[pos] = sc[src];
+                out_idx[pos] = si[src];
+            }
+            kept += __popcll(keep);
+        }
+        kept = kept < K ? kept : K;
+        for (int e = kept + lane; e < K; e += 64) {                  // padding: zero boxes (PSROIPool pools them to 0), index -1
+            reinterpret_cast<float4*>(out_boxes)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            out_conf[e] = 0.f;
+            out_idx[e] = -1;
+        }
+        if (lane == 0) *out_count = kept;
     }
-    if (tid == 0) *nsel = n;
 }
 
 __device__ __forceinline__ float box_iou(const float4& a, const float4& b)
@@ -186,38 +335,61 @@ k_region_mask(const float* __restrict__ sboxes, const int* __restrict__ nsel, un
     mask[(size_t)i * RG_W + cb] = m;
 }
 
-// One wave: greedy scan in blocks of 64 boxes.  Lane w owns word w of the `removed` bit set.  Inside a block the
-// 64 x 64 diagonal sub-mask decides serially which boxes survive; the survivors' rows are then OR-ed in in parallel.
-__global__ void __launch_bounds__(64)
+// Greedy scan in blocks of 64 boxes.  Wave 0 decides: lane w owns word w of the `removed` bit set; inside a block the
+// 64 x 64 diagonal sub-mask decides serially which boxes survive (the diagonal words sit in lanes and are read with
+// v_readlane: no memory access in the serial chain); the survivors' rows are then OR-ed into the later words in
+// parallel.  All 16 waves fetch: a block's rows (64 x up to 64 words) are one load per thread and register, issued
+// two blocks ahead, so that the chain of blocks never waits for memory (the first version -- one wave loading each
+// block's rows when it got there -- took 1.0 ms for 3000 boxes).
+__global__ void __launch_bounds__(RG_T)
 k_region_nms(const float* __restrict__ sboxes, const float* __restrict__ sconf, const int* __restrict__ sidx,
              const int* __restrict__ nsel, const unsigned long long* __restrict__ mask,
              float* __restrict__ out_boxes, float* __restrict__ out_conf, int* __restrict__ out_idx, int* __restrict__ out_count, int K)
 {
     __shared__ unsigned long long rows[64][RG_W + 1];
-    const int lane = threadIdx.x, n = *nsel, nblk = (n + 63) / 64;
-    unsigned long long removed = 0;                                  // word `lane`
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = *nsel, nblk = (n + 63) / 64;
+    constexpr int PER = 64 * RG_W / RG_T;                            // 4 words of a block per thread
+    int er[PER], ew[PER];                                            // which (row, word) of a block: the same for every block
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = tid + RG_T * q;
+        er[q] = nblk ? e / nblk : 64;                                // (rows >= 64: nothing to fetch)
+        ew[q] = nblk ? e - er[q] * nblk : 0;
+    }
+    struct Pre { unsigned long long v[PER]; };
+    auto fetch = [&](int blk) {                                      // words [blk, nblk) of the rows of block blk (earlier ones are unset)
+        Pre p;
+        const int nb = n - 64 * blk < 64 ? n - 64 * blk : 64;        // (<= 0 behind the last block)
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            p.v[q] = (er[q] < nb && ew[q] >= blk) ? mask[(size_t)(64 * blk + er[q]) * RG_W + ew[q]] : 0ull;
+        return p;
+    };
+    auto publish = [&](const Pre& p) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            if (er[q] < 64) rows[er[q]][ew[q]] = p.v[q];
+    };
+    unsigned long long removed = 0;                                  // wave 0: word `lane`
     int kept = 0;
-    for (int blk = 0; blk < nblk; ++blk) {
+    auto decide = [&](int blk) {                                     // wave 0 only
         const int nb = n - 64 * blk < 64 ? n - 64 * blk : 64;
-        for (int e = lane; e < 64 * RG_W; e += 64) {                 // this block's rows, words >= blk (earlier ones are unset)
-            const int r = e / RG_W, w = e - r * RG_W;
-            rows[r][w] = (r < nb && w >= blk && 64 * w < n) ? mask[(size_t)(64 * blk + r) * RG_W + w] : 0ull;
-        }
-        __syncthreads();
-        // serial part: the block's own word of `removed`
+        const unsigned long long diag = lane < nb ? rows[lane][blk] : 0ull;
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
         unsigned long long rem = __shfl(removed, blk, 64), keep = 0;
-        for (int r = 0; r < nb; ++r)
-            if (!((rem >> r) & 1)) { keep |= 1ull << r; rem |= rows[r][blk]; }
-        // parallel part: every later word
-        if (lane > blk) {
+        for (int r = 0; r < nb; ++r) {
+            const unsigned long long d = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, r) |
+                                         ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, r) << 32);
+            if (!((rem >> r) & 1)) { keep |= 1ull << r; rem |= d; }
+        }
+        if (lane > blk && lane < nblk) {
             unsigned long long acc = removed;
             for (int r = 0; r < nb; ++r)
                 if ((keep >> r) & 1) acc |= rows[r][lane];
             removed = acc;
         }
         if (lane == blk) removed = rem;
-        // survivors of this block, in order
-        const bool mine = lane < nb && ((keep >> lane) & 1);
+        const bool mine = lane < nb && ((keep >> lane) & 1);         // survivors of this block, in order
         const int pos = kept + __popcll(keep & ((1ull << lane) - 1ull));
         if (mine && pos < K) {
             const int src = 64 * blk + lane;
@@ -226,8 +398,23 @@ k_region_nms(const float* __restrict__ sboxes, const float* __restrict__ sconf, 
             out_idx[pos] = sidx[src];
         }
         kept += __popcll(keep);
+    };
+    Pre p0 = fetch(0), p1 = fetch(1);
+    for (int blk = 0; blk < nblk; blk += 2) {
+        publish(p0);
         __syncthreads();
+        p0 = fetch(blk + 2);
+        if (wave == 0) decide(blk);
+        __syncthreads();
+        if (blk + 1 < nblk) {                                        // uniform
+            publish(p1);
+            __syncthreads();
+            p1 = fetch(blk + 3);
+            if (wave == 0) decide(blk + 1);
+            __syncthreads();
+        }
     }
+    if (wave != 0) return;
     kept = kept < K ? kept : K;
     for (int e = kept + lane; e < K; e += 64) {                      // padding: zero boxes (PSROIPool pools them to 0), index -1
         reinterpret_cast<float4*>(out_boxes)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -263,10 +450,25 @@ int region_filter_f32(const float* anchors, const float* offsets, const float* c
     hipLaunchKernelGGL(k_region_decode, dim3((A + 255) / 256), dim3(256), 0, st, anchors, offsets, confs, boxes, keys, A, conf_thresh);
     int ns = 64;
     while (ns < max_dets) ns <<= 1;
-    hipLaunchKernelGGL(k_region_topk, dim3(1), dim3(RG_T), 0, st, keys, boxes, confs, sboxes, sconf, sidx, nsel, A, max_dets, ns);
+    const int A4 = (A + 3) / 4;
+#define D2T_TOPK(NV, FUSED) hipLaunchKernelGGL((k_region_topk<NV, FUSED>), dim3(1), dim3(RG_T), 0, st, keys, boxes, confs, sboxes, sconf, sidx, \
+                                               nsel, out_boxes, out_conf, out_idx, out_count, A, max_dets, ns, iou_thresh)
+    const bool fused = max_dets <= RG_FUSE;
+    if (fused) {
+        if (A4 <= 3 * RG_T) D2T_TOPK(3, true);
+        else if (A4 <= 10 * RG_T) D2T_TOPK(10, true);
+        else if (A4 <= 20 * RG_T) D2T_TOPK(20, true);
+        else D2T_TOPK(0, true);
+        return launch_status();
+    }
+    if (A4 <= 3 * RG_T) D2T_TOPK(3, false);
+    else if (A4 <= 10 * RG_T) D2T_TOPK(10, false);
+    else if (A4 <= 20 * RG_T) D2T_TOPK(20, false);
+    else D2T_TOPK(0, false);
+#undef D2T_TOPK
     const int nb = (max_dets + 63) / 64;
     hipLaunchKernelGGL(k_region_mask, dim3(nb, nb), dim3(64), 0, st, sboxes, nsel, mask, iou_thresh);
-    hipLaunchKernelGGL(k_region_nms, dim3(1), dim3(64), 0, st, sboxes, sconf, sidx, nsel, mask, out_boxes, out_conf, out_idx, out_count, max_dets);
+    hipLaunchKernelGGL(k_region_nms, dim3(1), dim3(RG_T), 0, st, sboxes, sconf, sidx, nsel, mask, out_boxes, out_conf, out_idx, out_count, max_dets);
     return launch_status();
 }
 
