@@ -15,9 +15,10 @@
 //    result (Inf / NaN somewhere in the channel poisons the table) is recomputed in the reference's
 //    form from global memory.
 //  * PSROIPool forward keeps the reference's running sum (ps_roipool_cuda.cu:60-66): a workgroup
-//    stages ONE input channel in LDS and evaluates every output (t, bin) that reads it, for a chunk
-//    of RoIs, lane = RoI; results go to a (t*49+bin, RoI) buffer and are transposed to (RoI, t, bin).
-//    Bit-identical to the reference.
+//    stages the SEVEN input channels of one (target, bin row) in LDS, lane = RoI (RoIs ordered by cell
+//    size), and writes out[r][t][7i..7i+6] directly (round 3; the round-2 form -- one channel per
+//    workgroup, a (t*49+bin, RoI) buffer and a transposing pass -- remains for maps whose seven
+//    channels do not fit in LDS and for more than 4096 RoIs).  Bit-identical to the reference.
 //  The backward kernels live in d2t_pool_bwd.hip.
 #include <cstdlib>
 #include "d2t_kernels.hpp"
@@ -408,10 +409,202 @@ k_psroipool_fwd_chan(const float* __restrict__ fm, const int4* __restrict__ cell
     }
 }
 
-// Below this many (RoI, target) pairs the whole op is launch-bound and the single-launch
-// thread-per-output kernel (d2t_pool_bwd.hip) is the faster one (R=300: 14-18 us against 25-29 us);
-// above it the channel-resident kernel wins (R=3000, nT=31: 91 us against 129 us).
-static bool ps_fwd_small(int R, int nT) { return 1LL * R * nT < 40000; }
+// ---------------------------------------------------------------------------------------
+// PSROIPool forward, bin-row form (round 3).  The channel-resident kernel above spends ~580 lane-instructions
+// per output: every lane of a wave walks a cell of a different shape (the loops run to the largest), with clamped
+// loads and predicates in the innermost loop, and its results need a transposing pass.  Here:
+//  * k_ps_roi_order (one workgroup) orders the RoIs by the size of their cells (rows x columns, estimated from the
+//    RoI's extent) so that the 64 RoIs of a wave walk about the same number of rows and columns: a counting sort on
+//    LDS atomics with the RoIs held in registers (loads inside the counting loops made the first version 16 us, a
+//    ballot loop per distinct key of a wave -- ~30 steps for 64 random RoIs -- the second 11.6 us).  The order
+//    changes no value -- every output is computed on its own -- only which lanes share a wave.  (Exact per-bin-row shapes, evaluated and sorted by 7 workgroups, were measured too: the 24
+//    bin axes per thread made that pre-pass 22 us and the main kernel no faster.)
+//  * k_psroipool_fwd_rows: workgroup = (target t, bin row i, a share of the RoIs in that order).  The SEVEN channels
+//    (t+1)(7i+j) it reads are staged in LDS once (80 KB at 38 x 75; all loads of a thread are issued before the
+//    first LDS store -- staged batch by batch the workgroup spent 10 of its 14 us waiting for them) and the
+//    workgroup then walks its RoIs 1024 at a time: the share is sized so that the grid is about one workgroup per CU
+//    (LDS admits only one), i.e. the staging is paid once per (t, i), not once per 1024 RoIs.  A lane owns one RoI,
+//    evaluates its eight bin axes itself and keeps seven running sums -- seven independent chains, each in the
+//    reference's row-major order with its guarded divide (bit-identical; a masked step adds +0, which cannot change
+//    a sum that started at +0).  The seven results of a RoI are one 28-byte run of out[r][t][7i .. 7i+6]: written
+//    through a wave-private LDS patch, ~10 cache lines per store instruction instead of 64.  Workgroup ids are
+//    dealt so that the seven bin rows of a (t, share) run on ONE XCD at the same time: its L2 merges their runs into
+//    the 196 contiguous bytes of out[r][t][:].
+// ---------------------------------------------------------------------------------------
+constexpr int PR_T = 1024;                     // threads = RoIs per pass of a workgroup
+constexpr int PR_Q = 4;                        // staging loads per thread and channel in flight (PR_T * PR_Q pixels per round)
+constexpr int PR_MAXR = 4096;                  // most RoIs the sorted path takes (wave rows of the counting sort: 64)
+
+__global__ void __launch_bounds__(1024)
+k_ps_roi_order(const float* __restrict__ rois, int* __restrict__ perm, int R, int H, int W)
+{
+    __shared__ unsigned hist[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    constexpr int NR = PR_MAXR / 1024;
+    float4 roi[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {                                   // every load in flight before anything waits
+        const int r = q * 1024 + tid;
+        roi[q] = r < R ? reinterpret_cast<const float4*>(rois)[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    int key[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        float fh = roi[q].z * (float)H * (1.f / KT), fw = roi[q].w * (float)W * (1.f / KT);
+        fh = fh == fh ? fh : 0.f; fw = fw == fw ? fw : 0.f;          // NaN extents: any bucket will do
+        const int h = (int)fminf(fmaxf(fh, 0.f), 14.f) + 1, w = (int)fminf(fmaxf(fw, 0.f), 14.f) + 1;
+        key[q] = q * 1024 + tid < R ? h * 16 + w : -1;               // (cell rows, cell columns), each 1..15
+        if (key[q] >= 0) atomicAdd(&hist[key[q]], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {                                                  // exclusive scan of the 256 counts by one wave
+        unsigned c[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = hist[4 * tid + k]; sum += c[k]; }
+        unsigned incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += t;
+        }
+        unsigned run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hist[4 * tid + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+    unsigned pos[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) pos[q] = key[q] >= 0 ? atomicAdd(&hist[key[q]], 1u) : 0u;   // (order inside a bucket: arbitrary)
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+        if (key[q] >= 0) perm[pos[q]] = q * 1024 + tid;
+}
+
+__global__ void __launch_bounds__(PR_T)
+k_psroipool_fwd_rows(const float* __restrict__ fm, const float* __restrict__ rois, const int* __restrict__ perm,
+                     float* __restrict__ out, int R, int nT, int H, int W, int nshare, int per, int HWp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float* map = reinterpret_cast<float*>(lds_raw);                  // [7][HWp]
+    float* patch = map + KT * HWp;                                   // [waves][64 * 7]
+    int* patch_r = reinterpret_cast<int*>(patch + (PR_T / 64) * 64 * KT);   // [waves][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, HW = H * W;
+    // id -> (group = (t, share), bin row): the 7 rows of a group sit on one XCD (ids are dealt to the 8 XCDs round-robin)
+    const int L = blockIdx.x, slot = L >> 3, g = (slot / KT) * 8 + (L & 7), i = slot % KT;
+    if (g >= nT * nshare) return;
+    const int t = g / nshare, share = g - t * nshare;
+    for (int e0 = 0; e0 < HW; e0 += PR_T * PR_Q) {                   // (one round at 38 x 75)
+        float v[KT][PR_Q];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const float* src = fm + (size_t)((t + 1) * (KT * i + j)) * HW;   // ps_roipool_cuda.cu:58
+#pragma unroll
+            for (int q = 0; q < PR_Q; ++q) {
+                const int e = e0 + q * PR_T + tid;
+                v[j][q] = e < HW ? src[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int q = 0; q < PR_Q; ++q) {
+                const int e = e0 + q * PR_T + tid;
+                if (e < HW) map[j * HWp + e] = v[j][q];
+            }
+    }
+    __syncthreads();
+    const int k_end = (share + 1) * per < R ? (share + 1) * per : R;
+    float* mine = patch + wave * 64 * KT;
+    const size_t plane0 = (size_t)t * KK + KT * i;
+    for (int k0 = share * per; k0 < k_end; k0 += PR_T) {             // (per is a multiple of 64: waves stay whole)
+        const int k = k0 + tid;
+        if (k0 + (wave << 6) >= k_end) break;                        // wave-uniform; nothing below synchronises the workgroup
+        const bool live = k < k_end;
+        const int r = live ? perm[k] : -1;
+        int i0 = 0, i1 = 0, x0[KT], w[KT], wmax = 0;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) { x0[j] = 0; w[j] = 0; }
+        if (live) {                                                  // the cells of bin row i (ps_roipool_cuda.cu:45-54)
+            const float4 roi = reinterpret_cast<const float4*>(rois)[r];
+            bin_axis<float>(roi.x - roi.z / 2.f, roi.z / static_cast<float>(KT), i, H, i0, i1);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                int j1;
+                bin_axis<float>(roi.y - roi.w / 2.f, roi.w / static_cast<float>(KT), j, W, x0[j], j1);
+                w[j] = j1 - x0[j];
+                wmax = w[j] > wmax ? w[j] : wmax;
+            }
+        }
+        const int h = i1 - i0;
+        int hu = h, wu = h > 0 ? wmax : 0;                           // the wave's loop bounds
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int a = __shfl_xor(hu, off, 64), b = __shfl_xor(wu, off, 64);
+            hu = a > hu ? a : hu;
+            wu = b > wu ? b : wu;
+        }
+        hu = __builtin_amdgcn_readfirstlane(hu);
+        wu = __builtin_amdgcn_readfirstlane(wu);
+        float acc[KT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[j] = 0.f;
+        for (int yy = 0; yy < hu; ++yy) {
+            const bool yok = yy < h;
+            const float* row = map + (i0 + yy) * W;                  // (a masked lane may point anywhere: its value is dropped)
+            int lim[KT];
+            const float* p[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) { lim[j] = yok ? w[j] : 0; p[j] = row + j * HWp + x0[j]; }
+#pragma unroll 2
+            for (int xx = 0; xx < wu; ++xx) {
+                float v[KT];
+#pragma unroll
+                for (int j = 0; j < KT; ++j) v[j] = p[j][xx];
+#pragma unroll
+                for (int j = 0; j < KT; ++j)
+                    if (xx < lim[j]) acc[j] += v[j];                   // ascending x inside ascending y (:60-66)
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const int n = h * w[j];
+            float a = acc[j];
+            if (n > 0) a /= static_cast<float>(n);                   // guarded divide, :67-69
+            mine[lane * KT + j] = a;
+        }
+        patch_r[wave * 64 + lane] = r;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            const int idx = q * 64 + lane, rl = idx / KT, j = idx - rl * KT;
+            const int rr = patch_r[wave * 64 + rl];
+            if (rr >= 0) out[(size_t)rr * nT * KK + plane0 + j] = mine[idx];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static size_t ps_rows_lds(int H, int W) { return ((size_t)KT * (((size_t)H * W + 3) & ~(size_t)3) + (PR_T / 64) * 64 * (KT + 1)) * 4; }
+static bool ps_rows_fit(int R, int nT, int H, int W)
+{
+    return R <= PR_MAXR && ps_rows_lds(H, W) <= (size_t)LDS_MAX - 2048 && nT <= (1 << 20);
+}
+// shares of the RoI list per (t, bin row): about one workgroup per CU, whole waves per share
+static void ps_rows_shares(int R, int nT, int& nshare, int& per)
+{
+    nshare = 256 / (nT * KT);
+    nshare = nshare < 1 ? 1 : nshare;
+    per = ((R + nshare - 1) / nshare + 63) & ~63;
+    nshare = (R + per - 1) / per;
+}
+
+// Below this many (RoI, target) pairs the single-launch thread-per-output kernel (d2t_pool_bwd.hip) is the faster one
+// (R=300 nT=4: 5.9 us against 11.6 us for the two launches of the bin-row form); above it the bin-row form wins
+// (R=300 nT=21: 13.3 / 14.2, R=300 nT=31: 14.0 / 18.3, R=3000 nT=4: 14.8 / 21.0, R=3000 nT=31: 37.5 us against 90 us
+// for the channel-resident kernel + transpose and 129 us for the thread-per-output kernel).
+static bool ps_fwd_small(int R, int nT) { return 1LL * R * nT < 6000; }
 
 bool psroipool_fwd_supported(int R, int nT, int H, int W, int k)
 {
@@ -422,6 +615,7 @@ bool psroipool_fwd_supported(int R, int nT, int H, int W, int k)
 size_t psroipool_fwd_ws_bytes(int R, int nT, int H, int W, int k)
 {
     if (!psroipool_fwd_supported(R, nT, H, W, k) || ps_fwd_small(R, nT)) return 0;
+    if (ps_rows_fit(R, nT, H, W)) return align256((size_t)R * sizeof(int));
     return cellsT_bytes(R) + align256((size_t)nT * KK * R * sizeof(float));
 }
 
@@ -429,6 +623,17 @@ int psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int
                       void* ws, hipStream_t st)
 {
     if (ps_fwd_small(R, nT)) return psroipool_fwd_small_f32(fm, rois, out, R, nT, H, W, k, st);
+    if (ps_rows_fit(R, nT, H, W)) {
+        int* perm = static_cast<int*>(ws);
+        hipLaunchKernelGGL(k_ps_roi_order, dim3(1), dim3(1024), 0, st, rois, perm, R, H, W);
+        int nshare, per;
+        ps_rows_shares(R, nT, nshare, per);
+        D2T_ENSURE_DYNAMIC_LDS(k_psroipool_fwd_rows, LDS_MAX);
+        hipLaunchKernelGGL(k_psroipool_fwd_rows, dim3((nT * nshare + 7) / 8 * 8 * KT), dim3(PR_T), ps_rows_lds(H, W), st,
+                           fm, rois, perm, out, R, nT, H, W, nshare, per, (H * W + 3) & ~3);
+        return launch_status();
+    }
+    // maps too large for seven resident channels, or more than 4096 RoIs: one channel per workgroup + transposing pass
     int4* cellsT = static_cast<int4*>(ws);
     float* tmpT = reinterpret_cast<float*>(static_cast<char*>(ws) + cellsT_bytes(R));
     int rc = ps_cells_T(rois, cellsT, R, H, W, st);

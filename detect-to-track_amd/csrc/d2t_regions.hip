@@ -82,6 +82,43 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned& t
 
 __device__ __forceinline__ float box_iou(const float4& a, const float4& b);
 
+// The greedy decision of one block of 64 boxes, by ONE wave.  `diag`: lane r holds row r's word of the block itself;
+// rem: the block's word of the removed set.  Everything in the chain is wave-uniform, so it is kept in SGPRs
+// (readfirstlane / readlane, scalar bit tests): 64 dependent steps of a few scalar instructions, no memory access.
+__device__ __forceinline__ unsigned long long greedy_block(unsigned long long diag, unsigned long long& rem_io, int nb)
+{
+    const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+    unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)rem_io), rhi = __builtin_amdgcn_readfirstlane((unsigned)(rem_io >> 32));
+    unsigned klo = 0, khi = 0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)dlo, r), b = (unsigned)__builtin_amdgcn_readlane((int)dhi, r);
+        if (r < nb && !((rlo >> r) & 1u)) { klo |= 1u << r; rlo |= a; rhi |= b; }
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)dlo, 32 + r), b = (unsigned)__builtin_amdgcn_readlane((int)dhi, 32 + r);
+        if (32 + r < nb && !((rhi >> r) & 1u)) { khi |= 1u << r; rlo |= a; rhi |= b; }
+    }
+    rem_io = (unsigned long long)rlo | ((unsigned long long)rhi << 32);
+    return (unsigned long long)klo | ((unsigned long long)khi << 32);
+}
+// OR of the rows of the block's survivors (bits of the wave-uniform `keep`), word `col` of each: 8 LDS reads in flight
+template <typename RowFn>
+__device__ __forceinline__ unsigned long long or_kept_rows(unsigned long long keep, unsigned long long acc, RowFn row)
+{
+#pragma unroll 1
+    for (int r0 = 0; r0 < 64; r0 += 8) {
+        if (!((keep >> r0) & 0xffull)) continue;                     // wave-uniform
+        unsigned long long v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = row(r0 + k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc |= ((keep >> (r0 + k)) & 1ull) ? v[k] : 0ull;
+    }
+    return acc;
+}
+
 // One workgroup does everything behind the decode: radix-select the max_dets-th largest key, compact the survivors,
 // order them by (confidence descending, anchor index ascending), gather their boxes and -- when max_dets <= RG_FUSE
 // -- the IoU bit matrix and the greedy scan as well (FUSED), so a frame's proposals cost two launches.
@@ -206,7 +243,7 @@ k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes
             if (take && w < (unsigned)RG_MAXK) cand[w++] = ((unsigned long long)k << 32) | (unsigned)(0x7fffffff - a);   // ties: lower index = larger
         }
     }
-    const int n = (int)(tot < (unsigned)K ? tot : (unsigned)K);
+    const int n = __builtin_amdgcn_readfirstlane((int)(tot < (unsigned)K ? tot : (unsigned)K));   // (the same in every thread)
     __syncthreads();
 
     // ---- order: (key descending, anchor ascending).  Up to 1024 candidates: every thread ranks its own among all
@@ -271,19 +308,10 @@ k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes
         for (int blk = 0; blk < nw; ++blk) {
             const int nb = n - 64 * blk < 64 ? n - 64 * blk : 64;
             const unsigned long long diag = lane < nb ? msk[64 * blk + lane][blk] : 0ull;   // lane r: row r's own-block word
-            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-            unsigned long long rem = __shfl(removed, blk, 64), keep = 0;
-            for (int r = 0; r < nb; ++r) {
-                const unsigned long long d = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, r) |
-                                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, r) << 32);
-                if (!((rem >> r) & 1)) { keep |= 1ull << r; rem |= d; }
-            }
-            if (lane > blk && lane < nw) {
-                unsigned long long acc = removed;
-                for (int r = 0; r < nb; ++r)
-                    if ((keep >> r) & 1) acc |= msk[64 * blk + r][lane];
-                removed = acc;
-            }
+            unsigned long long rem = __shfl(removed, blk, 64);
+            const unsigned long long keep = greedy_block(diag, rem, nb);
+            if (lane > blk && lane < nw)
+                removed = or_kept_rows(keep, removed, [&](int r) { return msk[64 * blk + r][lane]; });
             if (lane == blk) removed = rem;
             const bool mine = lane < nb && ((keep >> lane) & 1);
             const int pos = kept + __popcll(keep & ((1ull << lane) - 1ull));
@@ -375,19 +403,10 @@ k_region_nms(const float* __restrict__ sboxes, const float* __restrict__ sconf, 
     auto decide = [&](int blk) {                                     // wave 0 only
         const int nb = n - 64 * blk < 64 ? n - 64 * blk : 64;
         const unsigned long long diag = lane < nb ? rows[lane][blk] : 0ull;
-        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        unsigned long long rem = __shfl(removed, blk, 64), keep = 0;
-        for (int r = 0; r < nb; ++r) {
-            const unsigned long long d = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, r) |
-                                         ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, r) << 32);
-            if (!((rem >> r) & 1)) { keep |= 1ull << r; rem |= d; }
-        }
-        if (lane > blk && lane < nblk) {
-            unsigned long long acc = removed;
-            for (int r = 0; r < nb; ++r)
-                if ((keep >> r) & 1) acc |= rows[r][lane];
-            removed = acc;
-        }
+        unsigned long long rem = __shfl(removed, blk, 64);
+        const unsigned long long keep = greedy_block(diag, rem, nb);
+        if (lane > blk && lane < nblk)
+            removed = or_kept_rows(keep, removed, [&](int r) { return rows[r][lane]; });
         if (lane == blk) removed = rem;
         const bool mine = lane < nb && ((keep >> lane) & 1);         // survivors of this block, in order
         const int pos = kept + __popcll(keep & ((1ull << lane) - 1ull));
