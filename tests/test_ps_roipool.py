@@ -161,6 +161,40 @@ def test_sorted_lists_backward_adversarial_rois(oracle):
     assert np.array_equal(gin, _n(_ext.ps_roipool_backward(_t(gout), _t(rois), H, W)))
 
 
+def test_bin_row_forward_adversarial_and_nonfinite_rois(oracle):
+    """The bin-row forward (d2t_pool_tuned.hip: RoIs ordered by cell size, seven channels in LDS) on the adversarial RoIs --
+    clamped, empty, reversed and one-pixel bins -- plus RoIs with huge, negative, infinite and NaN extents (their order
+    bucket is arbitrary, their cells are the reference's), bit for bit; and a map with non-finite pixels: a masked lane
+    reads pixels outside its cell and must drop them."""
+    from detect_to_track.models import _ext
+    nT, H, W, k = 16, 38, 75, 7
+    adv = np.asarray(ADVERSARIAL_ROIS, np.float32)
+    odd = np.array([[0.5, 0.5, 40.0, 40.0], [0.5, 0.5, -0.3, 0.4], [0.2, 0.8, np.inf, 0.1], [0.5, 0.5, np.nan, 0.2],
+                    [np.nan, 0.5, 0.2, 0.2], [0.3, 0.3, 0.2, -np.inf], [1e30, -1e30, 1e30, 1e30]], np.float32)
+    rois = np.concatenate([adv] * 20 + [odd] * 8 + [random_rois(400, 4)], 0)
+    rois = rois[np.random.default_rng(7).permutation(len(rois))]
+    assert len(rois) * nT >= 6000                                              # the bin-row form's dispatch threshold
+    fm = np.random.default_rng(8).standard_normal((nT * k * k, H, W)).astype(np.float32)
+    np.testing.assert_array_equal(_n(_ext.ps_roipool_forward(_t(fm), _t(rois), nT, k)), oracle.psroipool_fwd(fm, rois, nT, k))
+    fm[::5, ::7, ::3] = np.inf
+    fm[1::5, 3::7, 1::3] = np.nan
+    got, want = _n(_ext.ps_roipool_forward(_t(fm), _t(rois), nT, k)), oracle.psroipool_fwd(fm, rois, nT, k)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_array_equal(np.nan_to_num(got, nan=0.0), np.nan_to_num(want, nan=0.0))
+
+
+@pytest.mark.parametrize("case", [(5000, 2, 20, 30), (400, 16, 60, 100), (4096, 2, 38, 75), (1000, 7, 1, 1), (700, 9, 3, 300)], ids=str)
+def test_forward_dispatch_edges(case, oracle):
+    """More than 4096 RoIs and maps whose seven channels do not fit in LDS take the channel-resident kernel; exactly
+    4096 RoIs, a one-pixel map and a 3 x 300 map the bin-row form.  All bit-identical to the oracle."""
+    from detect_to_track.models import _ext
+    R, nT, H, W = case
+    rng = np.random.default_rng(R + nT)
+    rois = random_rois(R, R + 1)
+    fm = rng.random((nT * 49, H, W)).astype(np.float32)
+    np.testing.assert_array_equal(_n(_ext.ps_roipool_forward(_t(fm), _t(rois), nT, 7)), oracle.psroipool_fwd(fm, rois, nT, 7))
+
+
 def test_channel_collisions_and_unused_channels():
     """(t+1)*(i*k+j) is many-to-one (reference ps_roipool_cuda.cu:58): for nT=2,k=3 only 13 of 18
     channels are ever read; the gradient of the other 5 must be exactly zero."""
