@@ -22,6 +22,7 @@ namespace {
 constexpr int RG_MAXK = 4096;                 // most boxes that can survive the max-det filter
 constexpr int RG_T = 1024;                    // threads of the single-workgroup kernels
 constexpr int RG_W = RG_MAXK / 64;            // 64-bit words per NMS mask row
+constexpr int RG_BINS = 4096;                 // counters of a radix-select pass (12-bit digits)
 constexpr int RG_FUSE = 512;                  // most boxes the single-kernel path (top-k + IoU matrix + greedy scan) takes
 
 // monotone map float -> unsigned (larger float = larger key); 0 is reserved for "filtered out"
@@ -80,7 +81,7 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned& t
     return base + incl - v;
 }
 
-__device__ __forceinline__ float box_iou(const float4& a, const float4& b);
+__device__ __forceinline__ bool iou_exceeds(const float4& a, const float4& b, float thr);
 
 // The greedy decision of one block of 64 boxes, by ONE wave.  `diag`: lane r holds row r's word of the block itself;
 // rem: the block's word of the removed set.  Everything in the chain is wave-uniform, so it is kept in SGPRs
@@ -126,9 +127,6 @@ __device__ __forceinline__ unsigned long long or_kept_rows(unsigned long long ke
 // NV > 0: the thread keeps 4*NV keys in registers (ONE round of coalesced 16-byte loads for the whole selection;
 // the first version re-read the keys from memory in each of the four passes, 35 dependent load latencies per pass
 // for a 38 x 63 map, and was 0.26 ms).  NV == 0: any A, keys re-read per pass.
-// The 256-bin histogram of a pass is built with one leader per wave-instruction taking the count of all lanes that
-// share its bin (confidences share their exponent: in the first passes almost every key falls into one bin and
-// plain LDS atomics would serialise), the rest adding themselves; the bin holding the K-th key is found with a scan.
 template <int NV, bool FUSED>
 __global__ void __launch_bounds__(RG_T)
 k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes, const float* __restrict__ confs,
@@ -136,7 +134,7 @@ k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes
               float* __restrict__ out_boxes, float* __restrict__ out_conf, int* __restrict__ out_idx, int* __restrict__ out_count,
               int A, int K, int NS, float iou)
 {   // NS: the sorting network's size, the power of two >= K (<= RG_MAXK); keys is padded with zeros to a multiple of 4
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[RG_BINS];
     __shared__ unsigned long long cand[RG_MAXK];                     // candidates; later the fused path's bit matrix
     __shared__ unsigned wtot[RG_T / 64];
     __shared__ unsigned s_prefix[4], s_need[4], s_eq[4], s_found[4];
@@ -173,36 +171,38 @@ k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes
     };
     if (tid < 4) s_found[tid] = 0;
 
-    // ---- 4 passes of 8 bits, most significant first: `prefix` = the bits of the K-th largest key found so far
+    // ---- radix select, most significant digit first: 12 + 12 + 8 bits.  `prefix` = the bits of the K-th largest key
+    // found so far.  Plain LDS atomics: the keys that pass the confidence filter share two or three exponents, so an
+    // 8-bit first digit would send them all to two or three counters (64 lanes serialising on one address), while
+    // 12 bits spread them over dozens; a leader lane collecting the count of its bin per wave-instruction (the
+    // first version) cost three times the instructions of the atomic itself.
     unsigned prefix = 0, need = (unsigned)K, eq = 0;                  // need: rank still wanted among the keys matching the prefix
     bool found = true;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 20 : (pass == 1 ? 8 : 0);
+        const unsigned dmask = pass == 2 ? 0xffu : 0xfffu;
+        const unsigned hi_mask = pass == 0 ? 0u : (pass == 1 ? 0xfff00000u : 0xffffff00u);
+#pragma unroll
+        for (int q = 0; q < RG_BINS / RG_T; ++q) hist[q * RG_T + tid] = 0;
         __syncthreads();
-        const unsigned hi_mask = pass == 0 ? 0u : 0xffffffffu << (shift + 8);
         for_each_key([&](unsigned k, int) {
-            const bool valid = k != 0 && (k & hi_mask) == prefix;
-            const unsigned long long live = __ballot(valid);
-            if (live) {                                              // wave-uniform
-                const unsigned bin = (k >> shift) & 255u;
-                const int lead = __builtin_amdgcn_readfirstlane(__ffsll((long long)live) - 1);
-                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, lead);
-                const bool same = valid && bin == b;
-                const unsigned long long m = __ballot(same);
-                if (lane == lead) atomicAdd(&hist[b], (unsigned)__popcll(m));
-                if (valid && !same) atomicAdd(&hist[bin], 1u);
-            }
+            if (k != 0 && (k & hi_mask) == prefix) atomicAdd(&hist[(k >> shift) & dmask], 1u);
         });
         __syncthreads();
-        const unsigned cnt = tid < 256 ? hist[255 - tid] : 0u;        // bins from the top
+        unsigned c[RG_BINS / RG_T], sum = 0;                          // this thread's bins, from the top
+#pragma unroll
+        for (int q = 0; q < RG_BINS / RG_T; ++q) { c[q] = hist[RG_BINS - 1 - (tid * (RG_BINS / RG_T) + q)]; sum += c[q]; }
         unsigned total;
-        const unsigned before = block_exclusive_scan(cnt, total, wtot, lane, wave);
-        if (tid < 256 && before < need && before + cnt >= need) {    // exactly one thread, or none when total < need
-            s_prefix[pass] = prefix | ((unsigned)(255 - tid) << shift);
-            s_need[pass] = need - before;
-            s_eq[pass] = cnt;
-            s_found[pass] = 1u;
+        unsigned run = block_exclusive_scan(sum, total, wtot, lane, wave);
+#pragma unroll
+        for (int q = 0; q < RG_BINS / RG_T; ++q) {                    // exactly one (thread, q) holds the K-th key, or none when total < need
+            if (run < need && run + c[q] >= need) {
+                s_prefix[pass] = prefix | ((unsigned)(RG_BINS - 1 - (tid * (RG_BINS / RG_T) + q)) << shift);
+                s_need[pass] = need - run;
+                s_eq[pass] = c[q];
+                s_found[pass] = 1u;
+            }
+            run += c[q];
         }
         __syncthreads();
         if (!s_found[pass]) { found = false; break; }                // fewer than K valid keys: everything valid is taken
@@ -296,7 +296,7 @@ k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes
                 const float4 me = sb[i];
                 for (int j = 0; j < 64; ++j) {
                     const int c = 64 * w + j;
-                    if (c > i && c < n && box_iou(me, sb[c]) > iou) m |= 1ull << j;
+                    if (c > i && c < n && iou_exceeds(me, sb[c], iou)) m |= 1ull << j;
                 }
             }
             msk[i][w] = m;
@@ -333,14 +333,19 @@ k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes
     }
 }
 
-__device__ __forceinline__ float box_iou(const float4& a, const float4& b)
+// IoU(a, b) > thr, decided as the float quotient inter / uni would decide it (oracle/regions.py: float32 throughout).
+// The quotient is first estimated with v_rcp_f32 (error of a few 1e-7 for a value in [0, 1]); the IEEE division runs
+// only when the estimate is within 1e-6 of the threshold or not a number (uni <= 0: the pair scores 0).
+__device__ __forceinline__ bool iou_exceeds(const float4& a, const float4& b, float thr)
 {
     const float ai0 = a.x - a.z / 2.f, ai1 = a.x + a.z / 2.f, aj0 = a.y - a.w / 2.f, aj1 = a.y + a.w / 2.f;
     const float bi0 = b.x - b.z / 2.f, bi1 = b.x + b.z / 2.f, bj0 = b.y - b.w / 2.f, bj1 = b.y + b.w / 2.f;
     const float ih = fminf(ai1, bi1) - fmaxf(ai0, bi0), iw = fminf(aj1, bj1) - fmaxf(aj0, bj0);
     const float inter = (ih > 0.f ? ih : 0.f) * (iw > 0.f ? iw : 0.f);
     const float uni = a.z * a.w + b.z * b.w - inter;
-    return uni > 0.f ? inter / uni : 0.f;
+    const float q = inter * __builtin_amdgcn_rcpf(uni);
+    if (uni > 0.f && fabsf(q - thr) > 1e-6f && q <= 2.f) return q > thr;   // (q <= 2: its error stays below the margin)
+    return (uni > 0.f ? inter / uni : 0.f) > thr;
 }
 
 // mask[i][w] bit j: box 64w+j comes later than box i and overlaps it by more than `iou`
@@ -358,7 +363,7 @@ k_region_mask(const float* __restrict__ sboxes, const int* __restrict__ nsel, un
     unsigned long long m = 0;
     for (int j = 0; j < 64; ++j) {
         const int c = 64 * cb + j;
-        if (c > i && c < n && box_iou(me, col[j]) > iou) m |= 1ull << j;
+        if (c > i && c < n && iou_exceeds(me, col[j], iou)) m |= 1ull << j;
     }
     mask[(size_t)i * RG_W + cb] = m;
 }

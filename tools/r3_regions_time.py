@@ -7,7 +7,7 @@ from detect_to_track.models import _ext
 from detect_to_track.training import build_anchors
 
 dev = "cuda:0"
-for (h, w, k) in [(38, 63, 300), (38, 63, 3000), (38, 75, 300)]:
+for (h, w, k) in [(38, 63, 300), (38, 63, 16), (38, 63, 128), (38, 63, 512), (38, 63, 3000), (38, 75, 300)]:
     rng = np.random.default_rng(0)
     anchors = torch.from_numpy(build_anchors((h, w), [0.001, 0.004, 0.016, 0.064, 0.256], [0.5, 1.0, 2.0])).to(dev)
     A = anchors.shape[0]
