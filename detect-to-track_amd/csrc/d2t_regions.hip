@@ -380,6 +380,8 @@ k_region_nms(const float* __restrict__ sboxes, const float* __restrict__ sconf, 
              float* __restrict__ out_boxes, float* __restrict__ out_conf, int* __restrict__ out_idx, int* __restrict__ out_count, int K)
 {
     __shared__ unsigned long long rows[64][RG_W + 1];
+    __shared__ unsigned long long keepw[RG_W];                       // per block: its survivors ...
+    __shared__ int keptb[RG_W + 1];                                  // ... and how many came before them
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = *nsel, nblk = (n + 63) / 64;
     constexpr int PER = 64 * RG_W / RG_T;                            // 4 words of a block per thread
     int er[PER], ew[PER];                                            // which (row, word) of a block: the same for every block
@@ -413,16 +415,9 @@ k_region_nms(const float* __restrict__ sboxes, const float* __restrict__ sconf, 
         if (lane > blk && lane < nblk)
             removed = or_kept_rows(keep, removed, [&](int r) { return rows[r][lane]; });
         if (lane == blk) removed = rem;
-        const bool mine = lane < nb && ((keep >> lane) & 1);         // survivors of this block, in order
-        const int pos = kept + __popcll(keep & ((1ull << lane) - 1ull));
-        if (mine && pos < K) {
-            const int src = 64 * blk + lane;
-            reinterpret_cast<float4*>(out_boxes)[pos] = reinterpret_cast<const float4*>(sboxes)[src];
-            out_conf[pos] = sconf[src];
-            out_idx[pos] = sidx[src];
-        }
-        kept += __popcll(keep);
-    };
+        if (lane == 0) { keepw[blk] = keep; keptb[blk] = kept; }     // the survivors are written out behind the scan: a gather
+        kept += __popcll(keep);                                      // here would put memory latency (and, through the in-order
+    };                                                               // vmcnt, the prefetches) into every step of the chain
     Pre p0 = fetch(0), p1 = fetch(1);
     for (int blk = 0; blk < nblk; blk += 2) {
         publish(p0);
@@ -438,14 +433,25 @@ k_region_nms(const float* __restrict__ sboxes, const float* __restrict__ sconf, 
             __syncthreads();
         }
     }
-    if (wave != 0) return;
-    kept = kept < K ? kept : K;
-    for (int e = kept + lane; e < K; e += 64) {                      // padding: zero boxes (PSROIPool pools them to 0), index -1
+    if (wave == 0 && lane == 0) keptb[RG_W] = kept;
+    __syncthreads();
+    const int total = keptb[RG_W] < K ? keptb[RG_W] : K;
+    for (int src = tid; src < n; src += RG_T) {                      // survivors, in order
+        const int blk = src >> 6, l = src & 63;
+        const unsigned long long keep = keepw[blk];
+        const int pos = keptb[blk] + __popcll(keep & ((1ull << l) - 1ull));
+        if (((keep >> l) & 1) && pos < K) {
+            reinterpret_cast<float4*>(out_boxes)[pos] = reinterpret_cast<const float4*>(sboxes)[src];
+            out_conf[pos] = sconf[src];
+            out_idx[pos] = sidx[src];
+        }
+    }
+    for (int e = total + tid; e < K; e += RG_T) {                    // padding: zero boxes (PSROIPool pools them to 0), index -1
         reinterpret_cast<float4*>(out_boxes)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         out_conf[e] = 0.f;
         out_idx[e] = -1;
     }
-    if (lane == 0) *out_count = kept;
+    if (tid == 0) *out_count = total;
 }
 
 inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
