@@ -1410,7 +1410,10 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
     int small[MAXLV], ns = 0;
     for (int l = 0; l < nl; ++l) {
         const long long wide = 2LL * B * tiles_j * ((C[l] + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
-        if (bwd_variant != 1 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {   // any grid: the kernel cuts the channels to fit it
+        if (bwd_variant == 3 && corr_bwd8bf_supported(B, C[l], H, W, lay.ps, lay.cs)) {  // bf16 matrix pipe, operands split in three
+            const int rc = corr_bwd8bf_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st);
+            if (rc != D2T_OK) return rc;
+        } else if (bwd_variant != 1 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {   // any grid: the kernel cuts the channels to fit it
             const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st, bwd_variant == 2 ? 1 : 0);
             if (rc != D2T_OK) return rc;
         } else if (wide >= 100 && lay.cs == 1)

@@ -23,6 +23,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct Split { bf16x8 hi, mid, lo; };
 
@@ -52,7 +53,7 @@ __device__ __forceinline__ f32x4 mac6(const Split& a, const Split& b, f32x4 acc)
     return acc;
 }
 
-template <int MODE>   // 0 f32, 1 presplit, 2 inline (both), 3 inline B only
+template <int MODE>   // 0 f32, 1 presplit, 2 inline (both), 3 inline B only, 4 presplit with the K = 16 instruction (48 MFMAs)
 __global__ void __launch_bounds__(512) k_time(const float* __restrict__ src, float* __restrict__ sink, unsigned long long* __restrict__ cyc, int iters)
 {
     const int lane = threadIdx.x & 63;
@@ -66,7 +67,21 @@ __global__ void __launch_bounds__(512) k_time(const float* __restrict__ src, flo
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 0; it < iters; ++it) {                             // one iteration = K 128 for 4 tiles (4 accumulators)
-        if (MODE == 0) {
+        if (MODE == 4) {
+            const s16x4 p0 = __builtin_bit_cast(s16x4, __builtin_shufflevector(sa.hi, sa.hi, 0, 1, 2, 3)), p1 = __builtin_bit_cast(s16x4, __builtin_shufflevector(sb.hi, sb.hi, 0, 1, 2, 3));
+            const s16x4 p2 = __builtin_bit_cast(s16x4, __builtin_shufflevector(sa.mid, sa.mid, 0, 1, 2, 3)), p3 = __builtin_bit_cast(s16x4, __builtin_shufflevector(sb.lo, sb.lo, 0, 1, 2, 3));
+#pragma unroll
+            for (int k = 0; k < 8; ++k)                              // 8 blocks of 16 channels, 6 products each
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(p2, p3, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(p0, p3, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(p2, p1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(p0, p1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(p2, p2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(p0, p0, acc[t], 0, 0, 0);
+                }
+        } else if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 32; ++k)
 #pragma unroll
@@ -127,14 +142,15 @@ int main()
     std::uniform_real_distribution<float> u(0.f, 1.f);
     for (auto& v : h) v = u(rng);
     CK(hipMemcpy(src, h.data(), 4096, hipMemcpyHostToDevice));
-    const char* names[4] = {"f32 16x16x4 (32 MFMAs)", "bf16x3 presplit (24 MFMAs)", "bf16x3, A and B split per use", "bf16x3, B split per use"};
+    const char* names[5] = {"f32 16x16x4 (32 MFMAs)", "bf16x3 presplit (24 MFMAs)", "bf16x3, A and B split per use", "bf16x3, B split per use", "bf16x3 presplit, K=16 instr (48)"};
     for (int wpb = 256; wpb <= 512; wpb += 256)                      // 1 and 2 waves per SIMD
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 5; ++mode) {
             for (int rep = 0; rep < 2; ++rep) {
                 if (mode == 0) hipLaunchKernelGGL(k_time<0>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
                 if (mode == 1) hipLaunchKernelGGL(k_time<1>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
                 if (mode == 2) hipLaunchKernelGGL(k_time<2>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
                 if (mode == 3) hipLaunchKernelGGL(k_time<3>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
+                if (mode == 4) hipLaunchKernelGGL(k_time<4>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
                 CK(hipDeviceSynchronize());
             }
             std::vector<unsigned long long> c(wgs * (wpb / 64));

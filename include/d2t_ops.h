@@ -71,7 +71,7 @@ const char* d2t_error_string(int code);
  *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)
  *   D2T_IMPL_MFMA    the tuned path, demanded: correlation returns D2T_EINVAL when its preconditions
  *                    (d_max = 8, stride 1, W >= 20) do not hold; the pooling ops fall back to generic */
-enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA_STRIP16 = 3 };
+enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA_STRIP16 = 3, D2T_IMPL_BF16X3 = 4 };
 /*   D2T_IMPL_MFMA_STRIP16  as D2T_IMPL_MFMA, but the correlation backward always takes the 16-wave strip kernel
  *                          (the default before the 8-wave one existed): same-process A/B measurements */
 
