@@ -70,6 +70,9 @@ __device__ __forceinline__ Piece8 join8(const Piece4& a, const Piece4& b)
 }
 
 #define D2T_BFMFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define D2T_BFMFMA_A(a, b, c) ((ABL & 16) ? bf_nomfma((a), (b), (c)) : D2T_BFMFMA((a), (b), (c)))
+
+__device__ __forceinline__ f32x4 bf_nomfma(const bf16x8& a, const bf16x8& b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
 
 struct QuadBf { int off, info; };                                   // as Quad8 of d2t_corr_bwd8.hip: lo | hi << 8 | mask << 16
 
@@ -133,7 +136,7 @@ typedef std::integral_constant<int, 5> I5;
 
 #define D2T_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int role>
+template <int role, int ABL = 0>   // ABL: ablation mask for timing experiments (-DD2T_LAB): 1 no S reloads, 2 no tile stores, 4 no G requests, 8 no ring writes, 16 no MFMAs
 __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, const float* __restrict__ gout,
                                              const float* __restrict__ fm0, const float* __restrict__ fm1,
                                              float* __restrict__ g0, float* __restrict__ g1,
@@ -164,7 +167,7 @@ __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, c
     sv[2][1] = BF_OOR;                                               // block 2 has no second piece: zeros
     const int s_step = 4 * W * 4, ct_step = 16 * HW * 4;
     auto s_load = [&](int ss, int q, int half, int ct) -> f32x4 {
-        if (q == 2 && half == 1) return f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((q == 2 && half == 1) || ((ABL & 1) && ss > 0)) return (q == 2 && half == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{0.5f, 0.25f, 0.125f, 1.f};
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, sv[q][half] + ss * s_step + ct * ct_step, 0, 0);
         return __builtin_bit_cast(f32x4, v);
     };
@@ -193,19 +196,23 @@ __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, c
         *reinterpret_cast<bf16x4*>(at + BF_PLANE) = s.mid;
         *reinterpret_cast<bf16x4*>(at + 2 * BF_PLANE) = s.lo;
     };
-    auto g_put_all = [&](unsigned char* buf) {
+    auto g_put_part = [&](unsigned char* buf, int part) {            // part 0 / 1: tile columns 0, 1 / 2, 3
         if (tid >= BF_PROD) return;
-        f32x4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = quadbf_fix(gn[k], qd[k].info);
         if (!role) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) put8(buf, k, split4(v[k]));                                   // quad k = tile column k
+            for (int k = 0; k < 2; ++k) put8(buf, 2 * part + k, split4(quadbf_fix(gn[2 * part + k], qd[2 * part + k].info)));   // quad k = tile column k
         } else {
+            f32x4 v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) put8(buf, c, split4(f32x4{v[0][c], v[1][c], v[2][c], v[3][c]}));   // quad k = window column k
+            for (int k = 0; k < 4; ++k) v[k] = quadbf_fix(gn[k], qd[k].info);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {                            // quad k = window column k
+                const int cc = 2 * part + c;
+                put8(buf, cc, split4(f32x4{v[0][cc], v[1][cc], v[2][cc], v[3][cc]}));
+            }
         }
     };
+    auto g_put_all = [&](unsigned char* buf) { g_put_part(buf, 0); g_put_part(buf, 1); };
 
     // ---- tile stores: lane (pixel n, channels 4g..4g+3 of each c-tile)
     unsigned long long badt = 0;                                     // tiles this lane stored a non-finite value for (bit u mod 64)
@@ -261,6 +268,13 @@ __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, c
         bv.lo = *reinterpret_cast<const bf16x8*>(at + 2 * BF_PLANE);
     };
 
+    Piece8 sa[BF_CT], sn[BF_CT];                                     // S pieces of the current block / of the next one
+#pragma unroll
+    for (int ct = 0; ct < BF_CT; ++ct) {
+        sa[ct] = join8(split4(a4[0][0][ct]), split4(a4[0][1][ct]));
+        a4[0][0][ct] = s_load(1, 0, 0, ct); a4[0][1][ct] = s_load(1, 0, 1, ct);
+    }
+
     // One super-step: G(ss) from ring buffer `cur`, G(ss+1) written to buffer `nxt` in front of its one barrier.
     // LO/HI: live accumulators [LO, HI) -- the first two super-steps carry tiles -2/-1 in acc[0..1], the last two carry
     // tiles past the map in acc[3..4].
@@ -268,14 +282,10 @@ __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, c
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         auto block = [&](auto q_c) {
             constexpr int q = decltype(q_c)::value;
-            Piece8 sa[BF_CT], bvA, bvB;
+            constexpr int qn = q == BF_NB - 1 ? 0 : q + 1;           // the block whose S pieces are split under this block's MFMAs
+            const int ssn = q == BF_NB - 1 ? ss + 1 : ss;
+            Piece8 bvA, bvB;
             b_fetch(bvA, cur, q, LO);
-#pragma unroll
-            for (int ct = 0; ct < BF_CT; ++ct) sa[ct] = join8(split4(a4[q][0][ct]), split4(a4[q][1][ct]));
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int ct = 0; ct < BF_CT; ++ct) a4[q][hf][ct] = s_load(ss + 1, q, hf, ct);   // a whole super-step ahead
             D2T_PIN();
 #pragma unroll
             for (int a = LO; a < HI; ++a) {
@@ -285,29 +295,42 @@ __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, c
                 D2T_PIN();
                 // six piece products, smallest first, the two c-tiles interleaved (two independent accumulator chains)
 #pragma unroll
-                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA(sa[ct].lo, bv.hi, acc[ct][a]);
+                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA_A(sa[ct].lo, bv.hi, acc[ct][a]);
 #pragma unroll
-                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA(sa[ct].hi, bv.lo, acc[ct][a]);
+                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA_A(sa[ct].hi, bv.lo, acc[ct][a]);
 #pragma unroll
-                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA(sa[ct].mid, bv.mid, acc[ct][a]);
+                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA_A(sa[ct].mid, bv.mid, acc[ct][a]);
 #pragma unroll
-                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA(sa[ct].mid, bv.hi, acc[ct][a]);
+                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA_A(sa[ct].mid, bv.hi, acc[ct][a]);
 #pragma unroll
-                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA(sa[ct].hi, bv.mid, acc[ct][a]);
+                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA_A(sa[ct].hi, bv.mid, acc[ct][a]);
 #pragma unroll
-                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA(sa[ct].hi, bv.hi, acc[ct][a]);
+                for (int ct = 0; ct < BF_CT; ++ct) acc[ct][a] = D2T_BFMFMA_A(sa[ct].hi, bv.hi, acc[ct][a]);
                 D2T_PIN();
-                // the super-step's non-MFMA work, behind the first tile of a block (its MFMAs are queued)
+                // Everything that is not an MFMA goes BEHIND a tile's twelve queued MFMAs, a piece per tile: the tile store /
+                // the ring writes of G(ss+1) and the barrier / the requests for G(ss+2) behind the first two tiles, the
+                // split of the next block's S pieces (and their reload for the super-step after) behind the second and third.
                 if (a == LO) {
-                    if (q == 0) store_tile(done, ss - 3);            // complete since the end of the previous super-step
+                    if (q == 0) { if (!(ABL & 2)) store_tile(done, ss - 3); else asm volatile("" ::"v"(done[0]), "v"(done[1])); }   // complete since the end of the previous super-step
+                    if (q == 1 && !(ABL & 8)) g_put_part(ring + nxt * BF_BUF, 0);  // G(ss+1), requested a super-step ago
+                    if (q == 2 && !(ABL & 4)) g_load_all(ss + 2);    // past the map: out of range, zeros
+                }
+                if (a == LO + 1) {
                     if (q == 1) {
-                        g_put_all(ring + nxt * BF_BUF);              // G(ss+1), requested a super-step ago
+                        if (!(ABL & 8)) g_put_part(ring + nxt * BF_BUF, 1);
                         lds_barrier();                               // publish; `nxt` was last read two barriers ago
                     }
-                    if (q == 2) g_load_all(ss + 2);                  // past the map: out of range, zeros
-                    D2T_PIN();
+                    sn[0] = join8(split4(a4[qn][0][0]), split4(a4[qn][1][0]));
+                    a4[qn][0][0] = s_load(ssn + 1, qn, 0, 0); a4[qn][1][0] = s_load(ssn + 1, qn, 1, 0);   // a whole super-step ahead
                 }
+                if (a == LO + 2) {
+                    sn[1] = join8(split4(a4[qn][0][1]), split4(a4[qn][1][1]));
+                    a4[qn][0][1] = s_load(ssn + 1, qn, 0, 1); a4[qn][1][1] = s_load(ssn + 1, qn, 1, 1);
+                }
+                if (a <= LO + 2) D2T_PIN();
             }
+#pragma unroll
+            for (int ct = 0; ct < BF_CT; ++ct) sa[ct] = sn[ct];
         };
         block(I0{});
         block(I1{});
@@ -358,6 +381,7 @@ __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, c
 }
 #undef D2T_PIN
 
+template <int ABL>
 __global__ void __launch_bounds__(BF_T)
 k_corr_bwd_strip8bf(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
                     float* __restrict__ g0, float* __restrict__ g1,
@@ -366,8 +390,8 @@ k_corr_bwd_strip8bf(const float* __restrict__ gout, const float* __restrict__ fm
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];   // BF_LDS bytes
     const int bid = xcd_remap(blockIdx.x, gridDim.x);                // both roles of a batch item stay on one XCD: they share gradOut[b]
     const int tj = bid % tiles_j, role = (bid / tiles_j) & 1, b = bid / (2 * tiles_j);
-    if (role) stripbf_body<1>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
-    else stripbf_body<0>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
+    if (role) stripbf_body<1, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
+    else stripbf_body<0, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
 }
 
 }  // namespace
@@ -381,9 +405,19 @@ int corr_bwd8bf_f32(const float* gout, const float* fm0, const float* fm1, float
                     int B, int C, int H, int W, hipStream_t st)
 {
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
-    D2T_ENSURE_DYNAMIC_LDS(k_corr_bwd_strip8bf, BF_LDS);
-    hipLaunchKernelGGL(k_corr_bwd_strip8bf, dim3(2 * B * tiles_j, (C + BF_CH - 1) / BF_CH), dim3(BF_T), BF_LDS, st,
-                       gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
+#define D2T_BF_LAUNCH(ABLV)                                                                                        \
+    {                                                                                                              \
+        D2T_ENSURE_DYNAMIC_LDS(k_corr_bwd_strip8bf<ABLV>, BF_LDS);                                                 \
+        hipLaunchKernelGGL(k_corr_bwd_strip8bf<ABLV>, dim3(2 * B * tiles_j, (C + BF_CH - 1) / BF_CH), dim3(BF_T), BF_LDS, st, \
+                           gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);                                  \
+    }
+#ifdef D2T_LAB
+    static const int abl = lab_env_int("D2T_BF_ABL", 0);             // timing experiments only: results are wrong
+    if (abl == 1) D2T_BF_LAUNCH(1) else if (abl == 2) D2T_BF_LAUNCH(2) else if (abl == 4) D2T_BF_LAUNCH(4) else if (abl == 12) D2T_BF_LAUNCH(12)
+    else if (abl == 16) D2T_BF_LAUNCH(16) else if (abl == 15) D2T_BF_LAUNCH(15) else if (abl == 7) D2T_BF_LAUNCH(7) else
+#endif
+    D2T_BF_LAUNCH(0)
+#undef D2T_BF_LAUNCH
     return launch_status();
 }
 

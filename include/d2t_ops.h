@@ -73,7 +73,11 @@ const char* d2t_error_string(int code);
  *                    (d_max = 8, stride 1, W >= 20) do not hold; the pooling ops fall back to generic */
 enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA_STRIP16 = 3, D2T_IMPL_BF16X3 = 4 };
 /*   D2T_IMPL_MFMA_STRIP16  as D2T_IMPL_MFMA, but the correlation backward always takes the 16-wave strip kernel
- *                          (the default before the 8-wave one existed): same-process A/B measurements */
+ *                          (the default before the 8-wave one existed): same-process A/B measurements
+ *   D2T_IMPL_BF16X3        as D2T_IMPL_MFMA, but the correlation backward (reference layout, map at least 17 rows high)
+ *                          runs on the bf16 matrix pipe with every f32 operand split into three bf16 pieces (six piece
+ *                          products per product): as accurate as the f32 chain (<= 1e-5 of sum|terms|, deterministic), not
+ *                          the default -- an experiment kept selectable */
 
 /* ---------------- PointwiseCorrelation ---------------- */
 size_t d2t_corr_fwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size);

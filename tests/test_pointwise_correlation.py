@@ -199,6 +199,45 @@ def test_nonfinite_inputs_match_live_reference(case, impl, ref_modules):
                                    rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", [(8, 256, 38, 63), (3, 20, 38, 75), (2, 300, 21, 44), (1, 64, 17, 130), (2, 40, 40, 20)], ids=str)
+def test_bf16x3_backward(case, oracle):
+    """D2T_IMPL_BF16X3 (opt-in): the backward on the bf16 matrix pipe, every f32 operand split into three bf16 pieces, six
+    piece products per product (d2t_corr_bwd8bf.hip).  Held to the contract of the other gradients -- 1e-5 of the sum of
+    |terms| of an element, against the yardstick with the reference's f32 terms added in double -- deterministic, and
+    with signed data (cancellation: the error is relative to the terms, not to the result)."""
+    from detect_to_track.models import _ext
+    B, C, H, W = case
+    rng = np.random.default_rng(B * 1000 + C)
+    fm0, fm1 = rng.standard_normal((B, C, H, W)).astype(np.float32), rng.standard_normal((B, C, H, W)).astype(np.float32)
+    gout = rng.standard_normal((B, H, W, 17, 17)).astype(np.float32)
+    g0, g1 = _ext.pointwise_correlation_backward(_t(gout), _t(fm0), _t(fm1), 8, 1, 4)
+    (w0, w1), (m0, m1) = oracle.corr_bwd_acc64(gout, fm0, fm1, 8, 1)
+    oracle.assert_within_contract(_n(g0), w0, m0, 1e-5, "gradFM0, bf16x3")
+    oracle.assert_within_contract(_n(g1), w1, m1, 1e-5, "gradFM1, bf16x3")
+    h0, h1 = _ext.pointwise_correlation_backward(_t(gout), _t(fm0), _t(fm1), 8, 1, 4)
+    assert torch.equal(g0, h0) and torch.equal(g1, h1)
+
+
+def test_bf16x3_backward_nonfinite_and_huge_inputs(oracle):
+    """A piece of Inf / NaN is NaN and a finite value above the bf16 range rounds to Inf: either way the tile's
+    accumulators turn non-finite and the wave recomputes its region in the reference's form -- the non-finite pattern and
+    every finite value are those of the f32 kernels."""
+    from detect_to_track.models import _ext
+    B, C, H, W = 2, 40, 21, 29
+    torch.manual_seed(5)
+    fm0, fm1 = torch.rand(B, C, H, W, device=DEV), torch.rand(B, C, H, W, device=DEV)
+    gout = torch.rand(B, H, W, 17, 17, device=DEV)
+    fm1[0, 3, 5, 7] = float("inf"); fm0[1, 0, 9, 20] = float("nan"); gout[0, 6, 6, 3, 4] = float("-inf")
+    fm1[1, 7, 2, 3] = 3.4e38; fm0[0, 1, 1, 1] = -3.4e38; gout[1, 2, 2, 8, 8] = 1e-30
+    g0, g1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, 4)
+    r0, r1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, 1)
+    for got, want in ((g0, r0), (g1, r1)):
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        assert torch.equal(torch.isposinf(got), torch.isposinf(want)) and torch.equal(torch.isneginf(got), torch.isneginf(want))
+        fin = torch.isfinite(want)
+        torch.testing.assert_close(got[fin], want[fin], rtol=2e-5, atol=2e-3)   # elements next to the 3.4e38 values are ~1e37; the rest ~50
+
+
 def test_north_star_shape_properties():
     """B=8 C=256 38x63 d=8 (BASELINE.json metric shape): size-independent properties."""
     from detect_to_track.models import _ext
