@@ -195,6 +195,25 @@ def test_forward_dispatch_edges(case, oracle):
     np.testing.assert_array_equal(_n(_ext.ps_roipool_forward(_t(fm), _t(rois), nT, 7)), oracle.psroipool_fwd(fm, rois, nT, 7))
 
 
+@pytest.mark.parametrize("case", [(400, 16, 38, 63), (1200, 9, 20, 30)], ids=str)
+def test_nonfinite_gradout_gemm_backward(case):
+    """Inf / NaN in gradOut on the shapes that take the backward GEMM: 0 x Inf = NaN must not reach columns outside the
+    value's cell (the reference, ps_roipool_cuda.cu:131-139, only adds to the cell's own pixels): a poisoned task is
+    recomputed with exact membership.  Pattern and finite values as the type-generic kernel."""
+    from detect_to_track.models import _ext
+    R, nT, H, W = case
+    rng = np.random.default_rng(R + nT)
+    rois = _t(random_rois(R, 9))
+    gout = rng.standard_normal((R, nT, 7, 7)).astype(np.float32)
+    gout[3, 5, 2, 2] = np.inf; gout[R - 1, nT - 1, 6, 0] = -np.inf; gout[R // 2, 1, 0, 6] = np.nan
+    got = _ext.ps_roipool_backward(_t(gout), rois, H, W)
+    want = _ext.ps_roipool_backward(_t(gout), rois, H, W, 1)
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert torch.equal(torch.isposinf(got), torch.isposinf(want)) and torch.equal(torch.isneginf(got), torch.isneginf(want))
+    fin = torch.isfinite(want)
+    torch.testing.assert_close(got[fin], want[fin], rtol=2e-5, atol=2e-4)
+
+
 def test_channel_collisions_and_unused_channels():
     """(t+1)*(i*k+j) is many-to-one (reference ps_roipool_cuda.cu:58): for nT=2,k=3 only 13 of 18
     channels are ever read; the gradient of the other 5 must be exactly zero."""

@@ -173,6 +173,26 @@ def test_nonfinite_map(impl, oracle):
     np.testing.assert_allclose(out[fin], want[fin], **TOL32)
 
 
+@pytest.mark.parametrize("case", [(64, 70, 38, 63), (300, 40, 20, 100)], ids=str)
+def test_nonfinite_gradout(case):
+    """Inf / NaN in gradOut.  The backward GEMM (d2t_pool_bwd.hip) multiplies every slot by a 0/1 weight for all 16 columns of a
+    tile: 0 x Inf = NaN would reach columns outside the value's bin, which the reference (roipool_cuda.cu:111-117) never
+    touches; a task that stored a non-finite value is recomputed with exact membership.  Pattern and finite values as the
+    type-generic kernel (the reference's form)."""
+    from detect_to_track.models import _ext
+    R, C, H, W = case
+    rng = np.random.default_rng(R)
+    rois = _t(random_rois(R, 5))
+    gout = rng.standard_normal((R, C, 7, 7)).astype(np.float32)
+    gout[3, 5, 2, 2] = np.inf; gout[R - 1, C - 1, 6, 0] = -np.inf; gout[R // 2, 17, 0, 6] = np.nan; gout[7, 0, 3, 3] = 3e38; gout[8, 0, 3, 3] = 3e38
+    got = _ext.roipool_backward(_t(gout), rois, H, W, 2)
+    want = _ext.roipool_backward(_t(gout), rois, H, W, 1)
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert torch.equal(torch.isposinf(got), torch.isposinf(want)) and torch.equal(torch.isneginf(got), torch.isneginf(want))
+    fin = torch.isfinite(want)
+    torch.testing.assert_close(got[fin], want[fin], rtol=2e-5, atol=2e-4)
+
+
 def test_config3_properties():
     """R=300 C=1024 38x63 k=7 (BASELINE.json config 3): size-independent properties."""
     from detect_to_track.models import _ext
