@@ -4,7 +4,7 @@
 // but every f32 operand x is carried as three bf16 pieces, x = hi + mid + lo exactly (8 + 8 + 8 mantissa bits), and a
 // product keeps six of the nine piece products (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi; the dropped ones are below
 // 2^-24 of the product), accumulated in f32 by v_mfma_f32_16x16x32_bf16.  Measured in csrc/lab/bf16x3_lab: 24 such MFMAs
-// do the K = 128 of 32 v_mfma_f32_16x16x4_f32 in 0.38x the time, and the result is as close to the exact sum as the f32
+// do the K = 128 of 32 v_mfma_f32_16x16x4_f32 in 0.46x the time (wall clock), and the result is as close to the exact sum as the f32
 // chain is (<= 1.1e-6 of sum|terms| at K = 2048 against 1.7e-6).  The backward's contract is 1e-5 (the reference adds with
 // atomics in no fixed order); this kernel is deterministic like the f32 one.
 //

@@ -3,7 +3,8 @@
 // bf16 pieces (x = hi + mid + lo, 6 of the 9 piece products kept: hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi)?
 //
 // Timing (every wave of the chip, operands in registers, 4 independent accumulators as in the product kernels;
-// cycles per K = 128 channels of one 16 x 16 tile, from s_memtime):
+// s_memtime ticks per K = 128 channels of 4 tiles AND wall-clock time per MFMA per SIMD from HIP events -- trust the
+// latter: under full matrix load the s_memtime counter slows down with the clock):
 //   f32      32 x v_mfma_f32_16x16x4_f32                               (the product's instruction)
 //   presplit 24 x v_mfma_f32_16x16x32_bf16 on pieces split beforehand  (the matrix time alone)
 //   inline   the same with BOTH operands split in registers per use    (no reuse of a split: worst case)
@@ -54,7 +55,7 @@ __device__ __forceinline__ f32x4 mac6(const Split& a, const Split& b, f32x4 acc)
 }
 
 template <int MODE>   // 0 f32, 1 presplit, 2 inline (both), 3 inline B only, 4 presplit with the K = 16 instruction (48 MFMAs)
-__global__ void __launch_bounds__(512) k_time(const float* __restrict__ src, float* __restrict__ sink, unsigned long long* __restrict__ cyc, int iters)
+__global__ void __launch_bounds__(1024) k_time(const float* __restrict__ src, float* __restrict__ sink, unsigned long long* __restrict__ cyc, int iters)
 {
     const int lane = threadIdx.x & 63;
     f32x8 xa, xb;
@@ -136,29 +137,37 @@ int main()
     // ---- timing
     const int wgs = 256, iters = 2000;
     float *src, *sink; unsigned long long* cyc;
-    CK(hipMalloc(&src, 1024 * 4)); CK(hipMalloc(&sink, wgs * 512 * 4)); CK(hipMalloc(&cyc, wgs * 8 * 8));
+    CK(hipMalloc(&src, 1024 * 4)); CK(hipMalloc(&sink, wgs * 1024 * 4)); CK(hipMalloc(&cyc, wgs * 16 * 8));
     std::vector<float> h(1024);
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> u(0.f, 1.f);
     for (auto& v : h) v = u(rng);
     CK(hipMemcpy(src, h.data(), 4096, hipMemcpyHostToDevice));
     const char* names[5] = {"f32 16x16x4 (32 MFMAs)", "bf16x3 presplit (24 MFMAs)", "bf16x3, A and B split per use", "bf16x3, B split per use", "bf16x3 presplit, K=16 instr (48)"};
-    for (int wpb = 256; wpb <= 512; wpb += 256)                      // 1 and 2 waves per SIMD
+    for (int wpb = 256; wpb <= 1024; wpb *= 2)                       // 1, 2 and 4 waves per SIMD
         for (int mode = 0; mode < 5; ++mode) {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            float ms = 0.f;
             for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(e0, 0));
                 if (mode == 0) hipLaunchKernelGGL(k_time<0>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
                 if (mode == 1) hipLaunchKernelGGL(k_time<1>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
                 if (mode == 2) hipLaunchKernelGGL(k_time<2>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
                 if (mode == 3) hipLaunchKernelGGL(k_time<3>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
                 if (mode == 4) hipLaunchKernelGGL(k_time<4>, dim3(wgs), dim3(wpb), 0, 0, src, sink, cyc, iters);
+                CK(hipEventRecord(e1, 0));
                 CK(hipDeviceSynchronize());
+                CK(hipEventElapsedTime(&ms, e0, e1));
             }
             std::vector<unsigned long long> c(wgs * (wpb / 64));
             CK(hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost));
             double mean = 0;
             for (auto v : c) mean += (double)v;
             mean /= c.size();
-            printf("%d wave(s)/SIMD  %-34s %9.1f s_memtime cycles per (K=128 x 4 tiles) per wave\n", wpb / 256, names[mode], mean / iters);
+            const double mfmas = (mode == 0 ? 128.0 : mode == 4 ? 192.0 : 96.0) * iters * (wpb / 256);   // per SIMD
+            printf("%d wave(s)/SIMD  %-34s %9.1f s_memtime cycles per (K=128 x 4 tiles) per wave; kernel %.3f ms = %.2f ns per MFMA per SIMD\n",
+                   wpb / 256, names[mode], mean / iters, ms, ms * 1e6 / mfmas);
         }
     // ---- numerics
     for (int dist = 0; dist < 2; ++dist)
