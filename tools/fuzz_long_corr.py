@@ -21,6 +21,9 @@ for it in range(N):
         g0, g1 = _ext.pointwise_correlation_backward(go, fm0, fm1, 8, 1, GENERIC)
         m0, m1 = _ext.pointwise_correlation_backward(go.abs(), fm0.abs(), fm1.abs(), 8, 1, GENERIC)
         assert bool(((t0 - g0).abs() <= 4e-6 * m0 + 1e-7).all()) and bool(((t1 - g1).abs() <= 4e-6 * m1 + 1e-7).all())
+        if H >= 17:                                                  # the bf16x3 backward (opt-in), same bar
+            s0, s1 = _ext.pointwise_correlation_backward(go, fm0, fm1, 8, 1, 4)
+            assert bool(((s0 - g0).abs() <= 4e-6 * m0 + 1e-7).all()) and bool(((s1 - g1).abs() <= 4e-6 * m1 + 1e-7).all()), "bf16x3"
     except Exception as e:
         bad += 1; print("CORR FAIL", (B, C, H, W), str(e)[:200], flush=True)
     if it % 20 == 19: print(f"{it + 1} cases, {bad} failures", flush=True)
