@@ -292,6 +292,7 @@ def run(args, device):
     # hipEventRecordWithFlags(..., hipEventRecordExternal) returns hipErrorInvalidValue, tools/r3_extev.py.)
     graph_replay = None
     if args.graph and hasattr(device, "capture"):
+        graph, err = None, None
         try:
             graph = device.capture(order)
             device.replay(graph)                                # untimed: instantiation / first launch
@@ -303,6 +304,15 @@ def run(args, device):
                 device.synchronize()
                 if not device.same(got, device.snapshot(order[-1])):
                     raise RuntimeError("graph replay and eager launches disagree")
+        except Exception as e:                                  # an extra measurement only
+            err = f"{type(e).__name__}: {str(e)[:160]}"
+            device.synchronize()
+        # every rank takes the same path through the collectives below: a rank whose capture failed must not leave
+        # the others waiting in a barrier (MAX over ranks of "failed")
+        failed = max_over_ranks(1.0 if err else 0.0, world, device.reduce_device()) > 0.0
+        if failed:
+            graph_replay = {"error": err or "graph capture failed on another rank"}
+        else:
             barrier()
             t0 = time.perf_counter()
             device.replay(graph)
@@ -310,9 +320,6 @@ def run(args, device):
             eg = max_over_ranks(time.perf_counter() - t0, world, device.reduce_device())
             graph_replay = {"ms_per_step": eg / K * 1e3, "value": whole_job_value(cnt["vox"], world, K, eg) / 1e9,
                             "note": "one hipGraph replay of the same K steps; not the metric"}
-        except Exception as e:                                  # an extra measurement only
-            graph_replay = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
-            device.synchronize()
 
     if rank == 0:
         ms = elapsed / K * 1e3
