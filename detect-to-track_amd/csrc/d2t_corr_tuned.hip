@@ -172,9 +172,8 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     // chunks staged past the end) is out of range and arrives as exact zeros without touching memory.
     // Columns outside the map read whatever neighbours them in memory: MFMA columns are independent
     // and those cells are masked in the epilogue.  Pad slots and pixel rows past the map are parked
-    // out of range.  Instruction y of a chunk (the 5 FM0 instructions first, then the FM1 ones in channel
-    // order) belongs to wave y mod 15: what a wave issues k-th holds lower channels than what it issues (k+1)-th,
-    // which is what the staged start of the first chunk (below) relies on.
+    // out of range.  Instruction y of a chunk (FM1 instructions first, then the 5 FM0 ones) belongs to
+    // wave y mod 15.
     constexpr int OOR = 0x7ffffff0;                                  // parked byte offset: always out of range
     const int P = (nrows * NCG + 15) & ~15;                          // slots per channel
     const int BPL = 4 * P;                                           // floats per channel plane
@@ -188,19 +187,19 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
 #pragma unroll
     for (int k = 0; k < SG_MAXDMA; ++k) {
         const int y = wave + SG_WAVES * k;
-        dA[k] = y < SG_AI;                                           // wave-uniform
+        dA[k] = y >= nBI;                                            // wave-uniform
         if (!dA[k]) {
-            const int e = (y - SG_AI) * 64 + lane;
+            const int e = y * 64 + lane;
             const int ch = (int)(((float)e + 0.5f) * rP), rem = e - ch * P;   // e / P, exact for e < 2^15
             const int row = rem / NCG, cg = rem - row * NCG;
             dv[k] = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 : OOR;
-            dl[k] = (y - SG_AI) * 256;
+            dl[k] = y * 256;
         } else {
-            const int e = y * 64 + lane;                             // FM0 piece: (channel, pixel row of the segment)
+            const int e = (y - nBI) * 64 + lane;                     // FM0 piece: (channel, pixel row of the segment)
             const int ch = e / (4 * SG_NU), prow = e - ch * (4 * SG_NU);
             const int i = 4 * u0 + prow;
             dv[k] = i < H ? (ch * HW + i * W + j0) * 4 : OOR;
-            dl[k] = a_base + y * 256;
+            dl[k] = a_base + (y - nBI) * 256;
         }
     }
     const int chunk_bytes = SG_KC * HW * 4;
@@ -213,26 +212,12 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, v, 0, 0, 0);
     };
     // "my instructions of the previous chunk have landed" (nd younger ones may be in flight) + barrier
-    auto wait_all_but = [&](int n) {                                 // n is wave-uniform
-        switch (n) {
-        case 0: dma_wait_barrier<0>(); break;
-        case 1: dma_wait_barrier<1>(); break;
-        case 2: dma_wait_barrier<2>(); break;
-        case 3: dma_wait_barrier<3>(); break;
-        case 4: dma_wait_barrier<4>(); break;
-        case 5: dma_wait_barrier<5>(); break;
-        case 6: dma_wait_barrier<6>(); break;
-        default: dma_wait_barrier<7>(); break;
-        }
-    };
-    auto wait_prev_chunk_and_barrier = [&]() { wait_all_but(nd < 4 ? nd : 4); };
-    // Staged start: chunk 0 is consumed k-step by k-step while it lands.  Behind "every wave's FIRST instruction of
-    // chunk 0 has landed" the ring holds all FM0 pixels and the FM1 slots below (15 - 5) * 64, i.e. channels 0-3
-    // (k-step 0) when the pitch is at most 160 slots; behind the second ones, the slots below 25 * 64 (channels 0-7).
-    const bool staged = P <= 160;                                    // else (35-row windows): wait for the whole chunk
-    auto wait_stage = [&](int s) {                                   // my instructions 0..s of chunk 0 have landed
-        const int left0 = nd - 1 - s > 0 ? nd - 1 - s : 0;          // (chunk 1's nd are younger still)
-        wait_all_but(nd + left0 < 7 ? nd + left0 : 7);
+    auto wait_prev_chunk_and_barrier = [&]() {
+        if (nd >= 4) dma_wait_barrier<4>();
+        else if (nd == 3) dma_wait_barrier<3>();
+        else if (nd == 2) dma_wait_barrier<2>();
+        else if (nd == 1) dma_wait_barrier<1>();
+        else dma_wait_barrier<0>();
     };
     using std::integral_constant;
     typedef integral_constant<int, 0> K0; typedef integral_constant<int, 1> K1;
@@ -310,28 +295,11 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         D2T_STAMP(12);
 #endif
-#define D2T_PIN() __builtin_amdgcn_sched_barrier(0)
-        int s_cur = 0, ch0 = 0;
-        if (staged) {                                                // chunk 0, started under its own arrival
-            wait_stage(0);
-            D2T_STAMP(1);
-            fetch(f0, smem, 0);
-            wait_stage(1);
-            fetch(f1, smem, 1); D2T_PIN(); mfma(f0, 0, 4); D2T_PIN();
-            wait_prev_chunk_and_barrier();                           // all of chunk 0 (chunk 1 in flight)
-            fetch(f0, smem, 2); D2T_PIN(); mfma(f1, 0, 4);
-            dma(2, 2, K0{}); dma(2, 2, K1{}); dma(2, 2, K2{}); dma(2, 2, K3{}); D2T_PIN();
-            fetch(f1, smem, 3); D2T_PIN(); mfma(f0, 0, 4); D2T_PIN();
-            wait_prev_chunk_and_barrier();                           // chunk 1 has landed
-            mfma(f1, 0, 2); D2T_PIN();
-            fetch(f0, smem + SG_BUF, 0); D2T_PIN(); mfma(f1, 2, 4); D2T_PIN();
-            s_cur = 1; ch0 = 1;
-        } else {
-            wait_prev_chunk_and_barrier();                           // chunk 0 has landed (chunk 1 may be in flight)
-            D2T_STAMP(1);
-            fetch(f0, smem, 0);
-        }
-        for (int ch = ch0; ch < nchunks; ++ch) {
+        wait_prev_chunk_and_barrier();                               // chunk 0 has landed (chunk 1 may be in flight)
+        D2T_STAMP(1);
+        fetch(f0, smem, 0);
+        int s_cur = 0;
+        for (int ch = 0; ch < nchunks; ++ch) {
             const int s_nxt = s_cur == SG_RING - 1 ? 0 : s_cur + 1;  // chunk ch+1
             const int s_fre = s_nxt == SG_RING - 1 ? 0 : s_nxt + 1;  // chunk ch-1: every wave has passed the barrier
             const float* cur = smem + s_cur * SG_BUF;                // behind its last read of that slot
@@ -339,6 +307,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
             // otherwise sinks it behind them and waits for the LDS round trip in front of every k-step);
             // a DMA instruction goes behind the MFMAs of a k-step.  Behind the barrier every wave of a
             // SIMD is released at once: each first issues MFMAs it already holds the operands of.
+#define D2T_PIN() __builtin_amdgcn_sched_barrier(0)
             fetch(f1, cur, 1); D2T_PIN(); mfma(f0, 0, 4); dma(s_fre, ch + 2, K0{}); D2T_PIN();
             fetch(f0, cur, 2); D2T_PIN(); mfma(f1, 0, 4); dma(s_fre, ch + 2, K1{}); dma(s_fre, ch + 2, K2{}); D2T_PIN();
             fetch(f1, cur, 3); D2T_PIN(); mfma(f0, 0, 4); dma(s_fre, ch + 2, K3{}); D2T_PIN();
