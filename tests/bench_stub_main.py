@@ -76,6 +76,6 @@ if __name__ == "__main__":
     stub = CpuStub()
     bench.run(a, stub)
     settle = min(3 * a.steps, 60)                                  # bounded untimed steps before the timed region
-    n = stub.n_sets + a.warmup + settle + a.steps * (3 if a.graph else 1)   # + the timed steps (+ 2 graph replays of them)
+    n = stub.n_sets + a.warmup + settle + a.steps * (4 if a.graph else 2)   # + the timed steps and the event pass (+ 2 graph replays of them)
     assert stub.calls == {"fwd": n, "bwd": n}, stub.calls
     print(f"stub rank {stub.rank} done", file=sys.stderr)

@@ -105,8 +105,10 @@ def test_bench_rank_skeleton_under_torchrun():
     assert d["ms_per_step"] >= 2 * (2 + 3) * 0.95, d["ms_per_step"]
     vox = bench.corr_counts(**bench.WORKLOADS["corr_B8_C256_38x63_d8"])["vox"]
     assert abs(d["value"] - 2 * vox / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
-    # value and kernels[] come from ONE pass: the kernels cannot outlast the step; the graph replay is an extra, not the metric
-    assert sum(k["us"] for k in d["kernels"]) <= d["ms_per_step"] * 1e3 * 1.001
+    # value: K steps with nothing else on the stream; kernels[]: the event intervals of a second pass, which tile THAT pass;
+    # the graph replay is an extra, not the metric
+    assert sum(k["us"] for k in d["kernels"]) <= d["event_pass"]["ms_per_step"] * 1e3 * 1.001
+    assert d["event_pass"]["records_per_step"] == 2
     assert d["timing"]["value"].startswith("wall time of K eager steps") and d["graph_replay"]["ms_per_step"] >= 2 * (2 + 3) * 0.95
     assert "cpu_baseline" not in d                          # rank 0 at N = 1 only
     assert p.stderr.count("stub rank") == 2
