@@ -381,8 +381,6 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
     constexpr int NACC = NCT * XT, NTHR = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __shared__ int s_bad;                                            // this task stored a non-finite value
-    if (tid == 0) s_bad = 0;
     // One task per workgroup; more workgroups than fit the chip, so the hardware dispatcher hands the next
     // task to whichever CU frees a slot -- a work queue without the ~3 us per task an atomic counter +
     // broadcast cost when tried.  Tasks are numbered from the MIDDLE rows outwards (mid, mid+1, mid-1, ...):
@@ -463,29 +461,26 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
                 const int c = c0 + 16 * ct + 4 * g + r;
                 if (c < C && col < W) gin[((size_t)c * H + y) * W + col] = v[r];
             }
-            if (__any(pool_nonfinite4(v)) && lane == 0) s_bad = 1;
+            // Cold path.  The matrix form multiplies every slot by a 0/1 weight for every column of a tile: an Inf / NaN in
+            // gradOut then reaches (0 x Inf = NaN) the columns outside its bin, which the reference (roipool_cuda.cu:111-117)
+            // never touches.  Whatever was poisoned is itself non-finite, so the wave that stored a non-finite value
+            // recomputes that 16 x 16 tile in the reference's form: a pixel adds only the slots whose bin contains it.
+            // (Wave-local on purpose: a workgroup-wide flag in static LDS pushed the kernel from 4 to 3 workgroups per CU.)
+            if (__builtin_expect(__any(pool_nonfinite4(v)), 0)) {
+                for (int e = lane; e < 256; e += 64) {
+                    const int c = c0 + 16 * ct + (e >> 4), xx = 16 * x + (e & 15);
+                    if (c >= C || xx >= W) continue;
+                    const float* gc = gout + (size_t)c * KK;
+                    float a = 0.f;
+                    for (int k = 0; k < 4 * nks; ++k) {
+                        const RmSlot sle = sl[k];
+                        if (sle.scale != 0.f && xx >= (sle.jb & 0xffff) && xx < (sle.jb >> 16)) a += gc[sle.goff] * sle.scale;
+                    }
+                    gin[((size_t)c * H + y) * W + xx] = a;
+                }
+            }
         }
         __syncthreads();                                             // red and list are free again
-        // Cold path.  The matrix form multiplies every slot by a 0/1 weight for every column of a tile: an Inf / NaN in
-        // gradOut then reaches (0 x Inf = NaN) the columns outside its bin, which the reference (roipool_cuda.cu:111-117)
-        // never touches.  Whatever was poisoned is itself non-finite, so a task that stored a non-finite value is
-        // recomputed in the reference's form: a pixel adds only the slots whose bin contains it.
-        if (__builtin_expect(s_bad, 0)) {
-            for (int e = tid; e < 16 * NCT * W; e += NTHR) {
-                const int c = c0 + e / W, x = e - (e / W) * W;
-                if (c >= C) continue;
-                const float* gc = gout + (size_t)c * KK;
-                float a = 0.f;
-                for (int k = 0; k < 4 * nks; ++k) {
-                    const RmSlot sle = sl[k];
-                    if (sle.scale != 0.f && x >= (sle.jb & 0xffff) && x < (sle.jb >> 16)) a += gc[sle.goff] * sle.scale;
-                }
-                gin[((size_t)c * H + y) * W + x] = a;
-            }
-            __syncthreads();
-            if (tid == 0) s_bad = 0;
-            __syncthreads();
-        }
     }
 }
 
@@ -516,7 +511,7 @@ static int roipool_bwd_mfma_f32(const float* gout, const float* rois, float* gin
 #define D2T_LAUNCH_GEMM(XTV, NCTV, NWV)                                                                        \
     {                                                                                                          \
         const size_t lds = 4 * RG_CH * sizeof(RmSlot) + (size_t)NWV * NCTV * XTV * 64 * sizeof(f32x4);         \
-        D2T_ENSURE_DYNAMIC_LDS((k_roipool_bwd_gemm<XTV, NCTV, NWV>), 159 * 1024);  /* + the static flag word */  \
+        D2T_ENSURE_DYNAMIC_LDS((k_roipool_bwd_gemm<XTV, NCTV, NWV>), 160 * 1024);                              \
         int per_cu = (int)((size_t)(160 * 1024) / (lds + 64));                                                 \
         const int by_waves = 16 / NWV;                                                                         \
         per_cu = per_cu > by_waves ? by_waves : per_cu;                                                        \
@@ -953,8 +948,6 @@ k_ps_bwd_gemm(const float* __restrict__ vt, const PgPair* __restrict__ lists, co
     const int y = (p & 1) ? (H - 1) / 2 + d : (H - 1) / 2 - d, i = bin / KT, j = bin - i * KT;
     const PgPair* src = lists + ((size_t)i * H + y) * R;
     const int cnt = counts[i * H + y];
-    __shared__ int s_bad;                                            // this task stored a non-finite value
-    if (tid == 0) s_bad = 0;
     const float* va = vt + (size_t)bin * R * nTp + n;                // + r * nTp + 16 * c-tile
     f32x4 acc[NCT][XT];
 #pragma unroll
@@ -1043,24 +1036,23 @@ k_ps_bwd_gemm(const float* __restrict__ vt, const PgPair* __restrict__ lists, co
             const int t = 16 * ct + 4 * g + r;
             if (t < nT && col < W) part[(((size_t)t * KK + bin) * H + y) * W + col] = v[r];
         }
-        if (__any(pool_nonfinite4(v)) && lane == 0) s_bad = 1;
-    }
-    __syncthreads();
-    // Cold path, as in k_roipool_bwd_gemm: a non-finite gradOut value times a 0 weight poisons columns outside its cell
-    // (the reference, ps_roipool_cuda.cu:131-139, only adds to the cell's own pixels); the task is recomputed with
-    // exact membership.
-    if (__builtin_expect(s_bad, 0)) {
-        for (int e = tid; e < nT * W; e += NTHR) {
-            const int t = e / W, x = e - t * W;
-            const float* vb = vt + (size_t)bin * R * nTp + t;
-            float a = 0.f;
-            for (int k = 0; k < cnt; ++k) {
-                const unsigned rh = src[k].rh;
-                const int jb = src[k].jb[j], j0 = jb & 0xffff, j1 = jb >> 16;
-                const int nn = (int)(rh >> 16) * (j1 - j0);
-                if (nn > 0 && x >= j0 && x < j1) a += vb[(size_t)(rh & 0xffff) * nTp] * (1.0f / static_cast<float>(nn));
+        // Cold path, as in k_roipool_bwd_gemm: a non-finite gradOut value times a 0 weight poisons columns outside its cell
+        // (the reference, ps_roipool_cuda.cu:131-139, only adds to the cell's own pixels); the wave recomputes the 16 x 16
+        // tile it stored with exact membership.
+        if (__builtin_expect(__any(pool_nonfinite4(v)), 0)) {
+            for (int e = lane; e < 256; e += 64) {
+                const int t = 16 * ct + (e >> 4), xx = 16 * x + (e & 15);
+                if (t >= nT || xx >= W) continue;
+                const float* vb = vt + (size_t)bin * R * nTp + t;
+                float a = 0.f;
+                for (int k = 0; k < cnt; ++k) {
+                    const unsigned rh = src[k].rh;
+                    const int jb = src[k].jb[j], j0 = jb & 0xffff, j1 = jb >> 16;
+                    const int nn = (int)(rh >> 16) * (j1 - j0);
+                    if (nn > 0 && xx >= j0 && xx < j1) a += vb[(size_t)(rh & 0xffff) * nTp] * (1.0f / static_cast<float>(nn));
+                }
+                part[(((size_t)t * KK + bin) * H + y) * W + xx] = a;
             }
-            part[(((size_t)t * KK + bin) * H + y) * W + x] = a;
         }
     }
 }
@@ -1098,7 +1090,7 @@ static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* g
 #define D2T_LAUNCH_PG(XTV, NCTV, NWV)                                                                          \
     {                                                                                                          \
         const size_t lds = PG_CH * sizeof(RmSlot) + (size_t)NWV * NCTV * XTV * 64 * sizeof(f32x4);             \
-        D2T_ENSURE_DYNAMIC_LDS((k_ps_bwd_gemm<XTV, NCTV, NWV>), 159 * 1024);       /* + the static flag word */  \
+        D2T_ENSURE_DYNAMIC_LDS((k_ps_bwd_gemm<XTV, NCTV, NWV>), 160 * 1024);                                   \
         hipLaunchKernelGGL((k_ps_bwd_gemm<XTV, NCTV, NWV>), dim3(ntasks), dim3(NWV * 64), lds, st, vt, lists, counts, part, R, nT, nTp, H, W); \
     }
 #define D2T_LAUNCH_PG_X(NCTV, NWV) { if (xt <= 4) D2T_LAUNCH_PG(4, NCTV, NWV) else if (xt <= 5) D2T_LAUNCH_PG(5, NCTV, NWV) else D2T_LAUNCH_PG(8, NCTV, NWV) }
