@@ -131,6 +131,9 @@ def max_over_ranks(seconds, world, device=None):
     return float(t.item())
 
 
+SETTLE_STEPS = 400   # untimed steps in front of the timed region: the clocks of a fresh box need ~50 ms of this load to settle
+
+
 def whole_job_value(units_per_rank_step, world, steps, elapsed_s):
     """Aggregate throughput: every rank processes its own shard (weak scaling, no exchange)."""
     return world * units_per_rank_step * steps / elapsed_s
@@ -270,7 +273,7 @@ def run(args, device):
     order = [(args.warmup + i) % n_sets for i in range(K)]
     # Untimed and bounded: the box is fresh and the W warmup steps are few -- let the clocks settle on this workload before
     # anything is timed (the driver's 25-step lines of rounds 1-2 sat 8-11 % below the 200-step ones for that reason).
-    for i in range(min(3 * K, 60)):
+    for i in range(min(3 * K, SETTLE_STEPS)):
         device.fwd(order[i % K])
         device.bwd(order[i % K])
     # The timed region (the metric): EXACTLY K steps launched on the stream between two barriers (+ device synchronize),
@@ -416,6 +419,7 @@ def run(args, device):
             "fwd_gvox_per_s": cnt["vox"] / kernels[0]["us"] / 1e3, "bwd_gvox_per_s": cnt["vox"] / kernels[1]["us"] / 1e3,
             "pct_hbm_roofline_fwd": 100 * kernels[0]["hbm"]["frac"],
             "pct_hbm_roofline_bwd": 100 * kernels[1]["hbm"]["frac"],
+            "settle_steps": min(3 * K, SETTLE_STEPS),
             "event_pass": {"ms_per_step": ms_ev, "records_per_step": 2, "event_record_overhead_us": record_us,
                            "host_ms_per_step_minus_device": ms_ev - t_dev},
             "graph_replay": graph_replay,

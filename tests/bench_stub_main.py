@@ -75,7 +75,7 @@ if __name__ == "__main__":
     a.no_cpu_baseline = True
     stub = CpuStub()
     bench.run(a, stub)
-    settle = min(3 * a.steps, 60)                                  # bounded untimed steps before the timed region
+    settle = min(3 * a.steps, bench.SETTLE_STEPS)                  # bounded untimed steps before the timed region
     n = stub.n_sets + a.warmup + settle + a.steps * (4 if a.graph else 2)   # + the timed steps and the event pass (+ 2 graph replays of them)
     assert stub.calls == {"fwd": n, "bwd": n}, stub.calls
     print(f"stub rank {stub.rank} done", file=sys.stderr)
