@@ -31,6 +31,10 @@ import sys
 import time
 from pathlib import Path
 
+# The host driver of this pool only supports dmabuf IPC: without this RCCL (and CUDA-tensor sharing across processes) fails
+# with "hipIpcGetMemHandle: invalid argument".  Must be in the environment before HIP initialises; harmless elsewhere.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
 

@@ -31,8 +31,13 @@ One JSON line on stdout (rank 0).  Not the headline metric (that is bench.py).
 """
 import argparse
 import json
+import os
 import sys
 import time
+
+# The host driver of this pool only supports dmabuf IPC: without this RCCL (and CUDA-tensor sharing across processes) fails
+# with "hipIpcGetMemHandle: invalid argument".  Must be in the environment before HIP initialises; harmless elsewhere.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 from collections import OrderedDict, defaultdict
 from pathlib import Path
 
