@@ -446,17 +446,22 @@ struct SplitLevels {
 __global__ void __launch_bounds__(SG_THREADS)
 k_corr_fwd_seg_split(SplitLevels lv, int B, int H, int W, int tiles_i, int tiles_j, int nseg, CellLayout lay)
 {
+    // logical id: the hardware deals workgroups to the 8 XCDs round-robin by blockIdx.x; give every XCD a contiguous run of
+    // the logical order (level, split, batch item, strip, segment), so that neighbouring segments -- whose windows overlap --
+    // share an L2.  (The map must be applied to the GLOBAL id: applied to the id inside a level or split, as at first, it
+    // only matches the hardware's dealing when that range starts at a multiple of 8.)
+    const int gl = xcd_remap(blockIdx.x, gridDim.x);
     int L = 0, wg0 = 0;
 #pragma unroll
     for (int l = 1; l < MAXLV; ++l)
-        if (l < lv.n && (int)blockIdx.x >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
+        if (l < lv.n && gl >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
     const float* fm0 = lv.fm0[0]; const float* fm1 = lv.fm1[0]; float* part = lv.part[0];
     int C = lv.C[0], S = lv.S[0], cps = lv.cps[0];
 #pragma unroll
     for (int l = 1; l < MAXLV; ++l)
         if (L == l) { fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; part = lv.part[l]; C = lv.C[l]; S = lv.S[l]; cps = lv.cps[l]; }
     const int nsegs = B * tiles_j * nseg;
-    const int lid = (int)blockIdx.x - wg0, s = lid / nsegs, bid = xcd_remap(lid - s * nsegs, nsegs);
+    const int lid = gl - wg0, s = lid / nsegs, bid = lid - s * nsegs;
     const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
     const int HW = H * W, c0 = s * cps * SG_KC;
     const int cn = C - c0 < cps * SG_KC ? C - c0 : cps * SG_KC;      // channels of this split (>= 1 by construction)
@@ -576,18 +581,19 @@ k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // level of this workgroup (wave-uniform scalar selects: the arrays live in kernel-argument SGPRs)
+    const int gl = xcd_remap(blockIdx.x, gridDim.x);                 // global logical id (see k_corr_fwd_seg_split)
     int L = 0, wg0 = 0;
 #pragma unroll
     for (int l = 1; l < MAXLV; ++l)
-        if (l < lv.n && (int)blockIdx.x >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
+        if (l < lv.n && gl >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
     const float* __restrict__ fm0 = lv.fm0[0];
     const float* __restrict__ fm1 = lv.fm1[0];
     float* __restrict__ out = lv.out[0];
-    int C = lv.C[0], nwg = lv.wg_end[0];
+    int C = lv.C[0];
 #pragma unroll
     for (int l = 1; l < MAXLV; ++l)
-        if (L == l) { fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; out = lv.out[l]; C = lv.C[l]; nwg = lv.wg_end[l] - lv.wg_end[l - 1]; }
-    const int bid = xcd_remap((int)blockIdx.x - wg0, nwg);
+        if (L == l) { fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; out = lv.out[l]; C = lv.C[l]; }
+    const int bid = gl - wg0;
     const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
     const int u0 = seg * NU, nu = tiles_i - u0 < NU ? tiles_i - u0 : NU;
     const int j0 = tj * TP, HW = H * W;
