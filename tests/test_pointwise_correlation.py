@@ -218,6 +218,22 @@ def test_bf16x3_backward(case, oracle):
     assert torch.equal(g0, h0) and torch.equal(g1, h1)
 
 
+@pytest.mark.parametrize("case", [(8, 256, 38, 63), (2, 512, 38, 75), (1, 260, 21, 30)], ids=str)
+def test_bf16x3_backward_matches_live_reference(case, ref_modules):
+    """The opt-in bf16x3 backward against the reference's own kernels on the same GPU, same inputs, at the tolerance the
+    default backward is held to (the headline shape included)."""
+    from detect_to_track.models import _ext
+    ref_corr = ref_modules[0]
+    B, C, H, W = case
+    torch.manual_seed(4321)
+    fm0, fm1 = torch.rand(B, C, H, W, device=DEV), torch.rand(B, C, H, W, device=DEV)
+    gout = torch.rand(B, H, W, 17, 17, device=DEV)
+    g0, g1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, 4)
+    r0, r1 = ref_corr.pointwise_correlation_backward(gout, fm0, fm1, 8, 1)
+    torch.testing.assert_close(g0, r0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, r1, rtol=1e-5, atol=1e-5)
+
+
 def test_bf16x3_backward_nonfinite_and_huge_inputs(oracle):
     """A piece of Inf / NaN is NaN and a finite value above the bf16 range rounds to Inf: either way the tile's
     accumulators turn non-finite and the wave recomputes its region in the reference's form -- the non-finite pattern and
