@@ -1247,11 +1247,14 @@ template <int ST_WAVES, int PROD_WAVES>                          // MFMA waves (
 __global__ void __launch_bounds__((ST_WAVES + PROD_WAVES) * 64)
 k_corr_bwd_strip_n(BwdLevels lv, int B, int H, int W, int tiles_i, int tiles_j, CellLayout lay)
 {
-    // level of this workgroup, then (strip, channel block) inside the level (wave-uniform)
+    // logical id (XCD-aware over the WHOLE grid: every XCD gets a contiguous run of the logical order, i.e. strips of the
+    // same channel block, which share the rows of S), then the level of this workgroup and (strip, channel block) inside
+    // it (wave-uniform)
+    const int gl = xcd_remap(blockIdx.x, gridDim.x);
     int L = 0, wg0 = 0;
 #pragma unroll
     for (int l = 1; l < MAXLV; ++l)
-        if (l < lv.n && (int)blockIdx.x >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
+        if (l < lv.n && gl >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
     const float* __restrict__ gout = lv.gout[0];
     const float* __restrict__ fm0 = lv.fm0[0];
     const float* __restrict__ fm1 = lv.fm1[0];
@@ -1261,7 +1264,7 @@ k_corr_bwd_strip_n(BwdLevels lv, int B, int H, int W, int tiles_i, int tiles_j, 
 #pragma unroll
     for (int l = 1; l < MAXLV; ++l)
         if (L == l) { gout = lv.gout[l]; fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; g0 = lv.g0[l]; g1 = lv.g1[l]; C = lv.C[l]; }
-    const int nstrips = 2 * B * tiles_j, lid = (int)blockIdx.x - wg0;
+    const int nstrips = 2 * B * tiles_j, lid = gl - wg0;
     const int blk_x = lid % nstrips, blk_y = lid / nstrips;
     constexpr int ST_THREADS = (ST_WAVES + PROD_WAVES) * 64;
     constexpr int ST_CH = ST_WAVES * 16;                             // channels per workgroup pass
@@ -1271,7 +1274,7 @@ k_corr_bwd_strip_n(BwdLevels lv, int B, int H, int W, int tiles_i, int tiles_j, 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool mfma_wave = PROD_WAVES == 0 || wave < ST_WAVES;       // wave-uniform
-    const int bid = xcd_remap(blk_x, nstrips);                       // (role, b) pairs stay on one XCD
+    const int bid = blk_x;
     const int tj = bid % tiles_j, b = (bid / tiles_j) % B, role = bid / (tiles_j * B);
     const int j0 = tj * TP, HW = H * W;
     const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
