@@ -135,7 +135,39 @@ def max_over_ranks(seconds, world, device=None):
     return float(t.item())
 
 
-SETTLE_STEPS = 400   # untimed steps in front of the timed region: the clocks of a fresh box need ~50 ms of this load to settle
+SETTLE_MS = 100.0     # untimed steps in front of the timed region until this much wall time has passed: the clocks of a fresh
+SETTLE_BATCH = 25     # box need ~50 ms of this load to settle (checked every SETTLE_BATCH steps; K = 20 and K = 200 then measure
+SETTLE_MAX_STEPS = 4000   # the same clocks)
+
+
+def sum_over_ranks(x, world, device=None):
+    """SUM over ranks (ranks_seen = an all-reduce of ones: how many ranks really took part)."""
+    if world == 1:
+        return x
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def launch_ranks(script, argv, n):
+    """`python3 bench.py --gpus N` launched bare (N > 1, no WORLD_SIZE in the environment): start the N ranks the way the
+    driver does -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per
+    GPU -- as a CHILD process, and hand its exit code back.  This parent never imports torch and never touches HIP (a
+    process that has initialised the GPU must not be replaced or forked into ranks on this pool); the ranks inherit stdout,
+    so rank 0's single JSON line is the only line printed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), *argv]
+    return subprocess.call(cmd, env=env)
 
 
 def whole_job_value(units_per_rank_step, world, steps, elapsed_s):
@@ -242,6 +274,10 @@ class HipDevice:
     def reduce_device(self):
         return self.dev
 
+    def ops_extra(self):
+        import bench_ops                                       # imports torch + the HIP library: never at module level here
+        return bench_ops.measure(self.dev, impl=self.impl, iters=20)
+
 
 def run(args, device):
     """The rank skeleton: init, setup, W warmup steps, EXACTLY K timed steps between barriers,
@@ -250,9 +286,10 @@ def run(args, device):
 
     rank, world, _ = rank_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: main() starts the ranks itself when launched bare")
     if world > 1:
         device.init_process_group()
+    ranks_seen = int(round(sum_over_ranks(1.0, world, device.reduce_device())))
 
     cfg = WORKLOADS[args.workload]
     B, C, H, W = (cfg[k] for k in "BCHW")
@@ -275,11 +312,19 @@ def run(args, device):
 
     K = args.steps
     order = [(args.warmup + i) % n_sets for i in range(K)]
-    # Untimed and bounded: the box is fresh and the W warmup steps are few -- let the clocks settle on this workload before
-    # anything is timed (the driver's 25-step lines of rounds 1-2 sat 8-11 % below the 200-step ones for that reason).
-    for i in range(min(3 * K, SETTLE_STEPS)):
-        device.fwd(order[i % K])
-        device.bwd(order[i % K])
+    # Untimed and bounded BY TIME, not by K: the box is fresh and the W warmup steps are few -- the chip ramps up under this
+    # load for ~50 ms -- so the same steps run untimed until args.settle_ms of wall time have passed (the driver's K = 20
+    # line of round 3 had min(3K, 400) = 60 settle steps = 7 ms and sat 8 % below the K = 200 line for that reason).
+    settle_steps, t_settle = 0, time.perf_counter()
+    while args.settle_ms > 0:
+        for i in range(SETTLE_BATCH):
+            device.fwd(order[(settle_steps + i) % K])
+            device.bwd(order[(settle_steps + i) % K])
+        settle_steps += SETTLE_BATCH
+        device.synchronize()
+        if (time.perf_counter() - t_settle) * 1e3 >= args.settle_ms or settle_steps >= SETTLE_MAX_STEPS:
+            break
+    settle_ms = (time.perf_counter() - t_settle) * 1e3
     # The timed region (the metric): EXACTLY K steps launched on the stream between two barriers (+ device synchronize),
     # nothing else on the stream.  value = vox of the K steps / wall time between the barriers.
     barrier()
@@ -379,6 +424,16 @@ def run(args, device):
                       "note": "K eager steps WITHOUT event records between the kernels, once with the D2T_IMPL_BF16X3 backward (bf16 MFMA, "
                               "operands split in three) and once with the default backward; neither is the metric"}
 
+    # Extra, NOT the metric (--ops 1, rank 0, a few seconds, after everything that is timed above): every other op / shape
+    # of the path -- config 2, the three correlations the model really runs, ROIPool / PSROIPool at config 3 and at the
+    # model's shapes -- through the C ABI with rotated buffers, each against its own roof (bench_ops.measure).
+    ops = None
+    if rank == 0 and args.ops and hasattr(device, "ops_extra"):
+        try:
+            ops = device.ops_extra()
+        except Exception as e:                                  # an extra measurement only
+            ops = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+
     if rank == 0:
         ms = elapsed / K * 1e3
         value = whole_job_value(cnt["vox"], world, K, elapsed) / 1e9
@@ -409,6 +464,23 @@ def run(args, device):
         record_us = (ms_ev - ms) * 1e3 / 2.0                    # two records per step
         for k in kernels:
             k["us_minus_record_overhead"] = k["us"] - record_us
+        # Third roof: the L1 / texture-address line rate.  lines = cache-line (tag) accesses per launch
+        # (TCP_TOTAL_CACHE_ACCESSES, PMC pass of the same command), peak = the chip-wide rate csrc/lab/ta_lab sustains with
+        # every CU streaming whole lines; both from profiles/ta_roof.json, the duration measured here.
+        ta = None
+        tafile = ROOT / "profiles" / "ta_roof.json"
+        if tafile.exists():
+            try:
+                ta = json.loads(tafile.read_text())
+            except Exception:
+                ta = None
+        for k in kernels:
+            k["roofline_ta"] = None
+            lines = ((ta or {}).get(args.workload) or {}).get(k["kernel"])
+            if ta and lines:
+                k["roofline_ta"] = dict(lines=lines, peak=ta["peak_lines_per_s"], unit="lines/s", achieved=lines / (k["us"] * 1e-6),
+                                        frac=lines / (k["us"] * 1e-6) / ta["peak_lines_per_s"], line_bytes=ta.get("line_bytes"),
+                                        clock_ghz=ta.get("clock_ghz"))
         line = {
             "metric": METRIC,
             "value": value, "unit": "Gvox/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -423,11 +495,12 @@ def run(args, device):
             "fwd_gvox_per_s": cnt["vox"] / kernels[0]["us"] / 1e3, "bwd_gvox_per_s": cnt["vox"] / kernels[1]["us"] / 1e3,
             "pct_hbm_roofline_fwd": 100 * kernels[0]["hbm"]["frac"],
             "pct_hbm_roofline_bwd": 100 * kernels[1]["hbm"]["frac"],
-            "settle_steps": min(3 * K, SETTLE_STEPS),
+            "settle_steps": settle_steps, "settle_ms": settle_ms, "ranks_seen": ranks_seen,
             "event_pass": {"ms_per_step": ms_ev, "records_per_step": 2, "event_record_overhead_us": record_us,
                            "host_ms_per_step_minus_device": ms_ev - t_dev},
             "graph_replay": graph_replay,
             "bf16x3_backward": bf16x3,
+            "ops": ops,
             "timing": {"value": "wall time of K eager steps between barriers, nothing else on the stream (ms_per_step)",
                        "kernels": "a second pass of the same K steps with a HIP event between the kernels: kernels[] / roofline are "
                                   "the event intervals, which tile event_pass.ms_per_step (asserted); an interval contains one "
@@ -440,6 +513,7 @@ def run(args, device):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return dict(settle_steps=settle_steps, ranks_seen=ranks_seen)
 
 
 def parse_args(argv=None):
@@ -453,12 +527,21 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1: also replay the K steps as one HIP graph (reported beside the metric)")
     ap.add_argument("--extras", type=int, default=1, help="1: also time the K steps with the opt-in bf16x3 backward (reported beside the metric)")
+    ap.add_argument("--ops", type=int, default=1, help="1: also time every other op / shape of the path (ops[] in the line, rank 0, ~3 s)")
+    ap.add_argument("--settle-ms", type=float, default=SETTLE_MS, help="untimed steps until this much wall time has passed (clock settling)")
     return ap.parse_args(argv)
 
 
-def main(argv=None):
+def main(argv=None, device_factory=None, script=None):
+    """`python3 bench.py --gpus N ...`.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank.  Launched
+    bare with N > 1 it is the GPU-free parent that starts the N ranks (launch_ranks) and exits with their code.
+    device_factory / script: the test harness (tests/bench_stub_main.py) runs the same entry with its own device layer."""
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
-    run(args, HipDevice(rank_env()[2], args.impl))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(script or Path(__file__).resolve(), argv, args.gpus))
+    device = device_factory() if device_factory else HipDevice(rank_env()[2], args.impl)
+    return run(args, device)
 
 
 if __name__ == "__main__":

@@ -62,6 +62,8 @@ def parse_args(argv=None):
     p.add_argument("--gpus", type=int, default=1, help="ranks (BASELINE config 5); launch with torch.distributed.run, one rank per GPU")
     p.add_argument("--bucket-mb", type=float, default=64.0, help="gradient all-reduce bucket size")
     p.add_argument("--backend", default="nccl", help="nccl = RCCL (one GPU per rank); gloo lets several ranks rehearse on ONE GPU")
+    p.add_argument("--exact-tracker", action="store_true", help="keep the tracker's correlation forward bit-identical to the reference (default dispatch) "
+                   "instead of D2T_IMPL_FAST")
     p.add_argument("--miopen-find", action="store_true", help="let MIOpen benchmark its convolution algorithms (torch.backends.cudnn.benchmark): "
                    "a long first step, faster library convolutions afterwards")
     return p.parse_args(argv)
@@ -102,14 +104,19 @@ class OpTimer:
 
 
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare (the way the driver launches N = 1): this process starts the N ranks as a child
+        # `python -m torch.distributed.run ...` BEFORE any torch.cuda / HIP call and exits with their code (bench.launch_ranks)
+        sys.path.insert(0, str(ROOT))
+        import bench
+        raise SystemExit(bench.launch_ranks(Path(__file__).resolve(), argv, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench_model.py needs an MI355X: the ops have no CPU path")
-    import os
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench_model.py --gpus {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: main() starts the ranks itself when launched bare")
     from detect_to_track.models import DetectTrackModule, _ext
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
@@ -135,6 +142,7 @@ def main(argv=None):
     timer = OpTimer(_ext)
     # cfg/default.yaml: resnet50, first trainable stage 3, 5 areas x 3 ratios = 15 anchors, 30 classes, k = 7, d_max = 8
     model = DetectTrackModule(args.backbone, 3, 15, 30, 7, 8, 7).to(dev)
+    model.c_tracker.fast_forward = not args.exact_tracker   # D2T_IMPL_FAST: the tracker's 1024 / 2048-channel levels split channels (within 1e-5)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     # cfg SGD_KWARGS with the learning rate turned down: random weights against random targets diverge at 1e-2 within two
@@ -156,6 +164,10 @@ def main(argv=None):
     n_steps = args.warmup + args.steps
     manager = SyntheticPairManager(world * B * n_steps, (H, W), n_anchor, R, Rt, 30, dev, seed=1)
     loader = iter(BatchLoader(manager, B, rank, world, seed=0))                  # every rank its own pairs
+    # Synthetic frames and targets are generated (and the tracked boxes copied host->device, a blocking copy) when a pair is
+    # indexed: draw every minibatch of the run BEFORE anything is timed, so that step_ms holds the training step only.
+    batches = iter([next(loader) for _ in range(n_steps)])
+    torch.cuda.synchronize()
     trainer = DataParallelTrainer(model, optim, coefs, regions, buckets)
     sections = DataParallelTrainer.SECTIONS
 
@@ -165,7 +177,7 @@ def main(argv=None):
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             return e
-        total, stamps, (b0e, b1e, b2e) = trainer.train_step(next(loader), mark)
+        total, stamps, (b0e, b1e, b2e) = trainer.train_step(next(batches), mark)
         if record is not None:
             record.append((stamps, b0e, b1e, b2e))
         return total

@@ -39,6 +39,9 @@ int check_pool(const void* fm, const void* rois, const void* out, int R, int C, 
     return D2T_OK;
 }
 
+// D2T_IMPL_MFMA .. D2T_IMPL_BF16X3 demand the tuned kernels (an unsupported shape is an error); AUTO / FAST fall back
+inline bool demands_tuned(int impl) { return impl >= D2T_IMPL_MFMA && impl <= D2T_IMPL_BF16X3; }
+
 inline size_t bins_bytes(int R, int k) { return align_up((size_t)R * k * k * 4 * sizeof(int32_t), 256); }
 
 }  // namespace
@@ -71,26 +74,26 @@ size_t d2t_corr_bwd_workspace_bytes(int B, int C, int H, int W, int d, int strid
 int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int stride,
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::corr_fwd_supported(B, C, H, W, d, stride)) {
-        // the workspace only enables the channel-split path of small grids (D2T_IMPL_AUTO); without it, or with
-        // D2T_IMPL_MFMA, the call runs the unsplit kernels, whose result is bit-identical to the reference
-        const bool split = impl == D2T_IMPL_AUTO && ws && ws_bytes >= tuned::corr_fwd_ws_bytes(B, C, H, W, d, stride);
+        // the channel-split path of small grids is an opt-in (D2T_IMPL_FAST + workspace); every other selector runs the
+        // unsplit kernels, whose result is bit-identical to the reference's ascending-channel chain
+        const bool split = impl == D2T_IMPL_FAST && ws && ws_bytes >= tuned::corr_fwd_ws_bytes(B, C, H, W, d, stride);
         return tuned::corr_fwd_f32(fm0, fm1, out, B, C, H, W, d, stride, split ? ws : nullptr, split ? ws_bytes : 0, as_stream(stream));
     }
-    if (impl >= D2T_IMPL_MFMA) return D2T_EINVAL;     // tuned path demanded but not applicable
+    if (demands_tuned(impl)) return D2T_EINVAL;     // tuned path demanded but not applicable
     return corr_fwd_generic<float>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
 }
 
 int d2t_corr_fwd_f64(const double* fm0, const double* fm1, double* out, int B, int C, int H, int W, int d, int stride,
                      void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
-    if (impl >= D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (demands_tuned(impl)) return D2T_EINVAL;
     return corr_fwd_generic<double>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -98,7 +101,7 @@ int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, floa
                      int B, int C, int H, int W, int d, int stride,
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
@@ -107,7 +110,7 @@ int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, floa
         return tuned::corr_bwd_f32(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, ws, as_stream(stream),
                                    impl == D2T_IMPL_MFMA_STRIP16 ? 1 : (impl == D2T_IMPL_BF16X3 ? 3 : 0));
     }
-    if (impl >= D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (demands_tuned(impl)) return D2T_EINVAL;
     return corr_bwd_generic<float>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -115,11 +118,11 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1, d
                      int B, int C, int H, int W, int d, int stride,
                      void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
-    if (impl >= D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (demands_tuned(impl)) return D2T_EINVAL;
     return corr_bwd_generic<double>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -151,7 +154,7 @@ int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* 
                             int B, int H, int W, int d, int stride, int layout, long long bstride,
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)out, C, B, H, W, d, stride, layout, bstride);
     if (rc != D2T_OK) return rc;
     const int cells = (2 * d + 1) * (2 * d + 1), HW = H * W;
@@ -160,10 +163,10 @@ int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* 
     bool tuned_ok = impl != D2T_IMPL_GENERIC;
     for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_fwd_supported(B, C[l], H, W, d, stride);
     if (tuned_ok) {
-        const bool split = impl == D2T_IMPL_AUTO && ws && ws_bytes >= tuned::corr_fwd_levels_ws_bytes(n, C, B, H, W);
+        const bool split = impl == D2T_IMPL_FAST && ws && ws_bytes >= tuned::corr_fwd_levels_ws_bytes(n, C, B, H, W);
         return tuned::corr_fwd_levels_f32(n, fm0, fm1, out, C, B, H, W, lay, as_stream(stream), split ? ws : nullptr, split ? ws_bytes : 0);
     }
-    if (impl >= D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (demands_tuned(impl)) return D2T_EINVAL;
     for (int l = 0; l < n; ++l) {
         rc = corr_fwd_generic<float>(fm0[l], fm1[l], out[l], B, C[l], H, W, d, stride, as_stream(stream), lay.ps, lay.cs, lay.bs);
         if (rc != D2T_OK) return rc;
@@ -176,7 +179,7 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
                             int B, int H, int W, int d, int stride, int layout, long long bstride,
                             void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)gout, C, B, H, W, d, stride, layout, bstride);
     if (rc != D2T_OK) return rc;
     if (!gfm0 || !gfm1) return D2T_EINVAL;
@@ -189,7 +192,7 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
     for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_bwd_supported(B, C[l], H, W, d, stride);
     if (tuned_ok) return tuned::corr_bwd_levels_f32(n, gout, fm0, fm1, gfm0, gfm1, C, B, H, W, lay, as_stream(stream),
                                                     impl == D2T_IMPL_MFMA_STRIP16 ? 1 : (impl == D2T_IMPL_BF16X3 ? 3 : 0));
-    if (impl >= D2T_IMPL_MFMA) return D2T_EINVAL;
+    if (demands_tuned(impl)) return D2T_EINVAL;
     for (int l = 0; l < n; ++l) {
         rc = corr_bwd_generic<float>(gout[l], fm0[l], fm1[l], gfm0[l], gfm1[l], B, C[l], H, W, d, stride, as_stream(stream),
                                      lay.ps, lay.cs, lay.bs);
@@ -213,13 +216,13 @@ size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int el
 int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_pool(fm, rois, out, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     // The tuned forward builds a summed-area table of every channel (the whole map is read once): for
     // a handful of RoIs (the tracker pools ~8 boxes of a 1891-channel map) the thread-per-output
     // kernel, which only touches the boxes' pixels, is the faster one.
-    const bool few_rois = impl == D2T_IMPL_AUTO && R < 32;
+    const bool few_rois = (impl == D2T_IMPL_AUTO || impl == D2T_IMPL_FAST) && R < 32;
     if (impl != D2T_IMPL_GENERIC && !few_rois && tuned::roipool_fwd_supported(R, C, H, W, k)) {
         if (ws_bytes < tuned::roipool_fwd_ws_bytes(R, C, H, W, k) || (!ws && ws_bytes)) return D2T_EWS;
         return tuned::roipool_fwd_f32(fm, rois, out, R, C, H, W, k, ws, as_stream(stream));
@@ -230,7 +233,7 @@ int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, i
 int d2t_roipool_fwd_f64(const double* fm, const double* rois, double* out, int R, int C, int H, int W, int k,
                         void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_pool(fm, rois, out, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     return roipool_fwd_generic<double>(fm, rois, out, R, C, H, W, k, as_stream(stream));
@@ -239,7 +242,7 @@ int d2t_roipool_fwd_f64(const double* fm, const double* rois, double* out, int R
 int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::roipool_bwd_supported(R, C, H, W, k)) {
@@ -253,7 +256,7 @@ int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R,
 int d2t_roipool_bwd_f64(const double* gout, const double* rois, double* gin, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
@@ -285,7 +288,7 @@ static int check_ps(const void* fm, const void* rois, const void* out, int R, in
 int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_ps(fm, rois, out, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && R > 0 && tuned::psroipool_fwd_supported(R, nT, H, W, k)) {
@@ -299,7 +302,7 @@ int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R,
 int d2t_psroipool_fwd_f64(const double* fm, const double* rois, double* out, int R, int nT, int H, int W, int k,
                           void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_ps(fm, rois, out, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     return psroipool_fwd_generic<double>(fm, rois, out, R, nT, H, W, k, as_stream(stream));
@@ -308,7 +311,7 @@ int d2t_psroipool_fwd_f64(const double* fm, const double* rois, double* out, int
 int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::psroipool_bwd_supported(R, nT, H, W, k)) {
@@ -322,7 +325,7 @@ int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int 
 int d2t_psroipool_bwd_f64(const double* gout, const double* rois, double* gin, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_BF16X3) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
@@ -369,6 +372,9 @@ int d2t_region_filter_f32(const float* anchors, const float* offsets, const floa
 {
     if (A < 0 || max_dets < 1 || max_dets > region_max_dets() || !out_boxes || !out_conf || !out_idx || !out_count) return D2T_EINVAL;
     if (A > 0 && (!anchors || !offsets || !confs)) return D2T_EINVAL;
+    // boxes are moved as float4 / u32x4: a pointer that is only 4-byte aligned would fault on the device
+    if (((reinterpret_cast<uintptr_t>(anchors) | reinterpret_cast<uintptr_t>(offsets) | reinterpret_cast<uintptr_t>(out_boxes) |
+          reinterpret_cast<uintptr_t>(ws)) & 15) != 0) return D2T_EINVAL;
     if (!fits_i32(4LL * A)) return D2T_ETOOBIG;
     if (A == 0) {                                                    // nothing to filter: an all-padding list
         hipError_t e = hipMemsetAsync(out_boxes, 0, (size_t)max_dets * 16, as_stream(stream));

@@ -138,6 +138,9 @@ typedef std::integral_constant<int, 5> I5;
 // skipped behind wave-uniform branches.  That lets the host cut the channels of a SMALL grid (the model's B = 1 pairs:
 // 32-38 strips) into as many blocks as fill the chip once, instead of 256-channel blocks that fill 60 % of it (C = 1024)
 // or need a second, nearly empty round (C = 2048).  !FLEX: 256 channels, wave w = c-tiles 2w, 2w + 1, no branches.
+#ifndef D2T_EXP_GCO
+#define D2T_EXP_GCO 1
+#endif
 template <int role, int S8_CT, bool ROWKB, int ABL = 0, bool FLEX = false>    // ABL: ablation mask of csrc/lab/bwd8_stamp_lab (timing only)
 __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const float* __restrict__ gout,
                                             const float* __restrict__ fm0, const float* __restrict__ fm1,
@@ -183,9 +186,26 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     // hardware favours at the matrix pipe, they reach every barrier a quarter of a super-step early -- producing all
     // of G in two batches: 72 -> 83 us; alternating s_setprio between the two waves of a SIMD: no change.)
     const int gtid = tid;
+    // Which ring quad does production slot ep = tid + GT k fill?  Role 0: the 20 quads of one tile pixel and super-step
+    // (4 window rows x 5 column groups) are 68 CONSECUTIVE floats of gradOut (rows ci .. ci+3 of the pixel's 17 x 17 cell
+    // block), so consecutive lanes take the pieces of ONE pixel in memory order: a wave-instruction then touches the ~5
+    // cache lines of each of its 3.2 pixels (about 17 lines) instead of 2 lines per (pixel, row) in 64 different cell blocks.
+    // Role 1 keeps ring order (its 16-byte pieces lie 68 bytes apart whatever the order).
+    constexpr bool GCO = D2T_EXP_GCO && ROWKB && role == 0;
+    auto ring_index = [&](int ep) -> int {
+        if (!GCO || ep >= S8_QUADS) return ep;
+        const int p = (ep * 3277) >> 16, m = ep - p * 20;              // ep / 20 (ep < 1600): pixel of the 5 live tiles, piece of its 4 x 5
+        const int a = p >> 4, pix = p & 15, xr = (m * 13) >> 6, cg = m - xr * 5;
+        const int q = cg < 4 ? xr : 4, gg = cg < 4 ? cg : xr;
+        return (q * NACT + a) * 64 + gg * 16 + pix;
+    };
     Quad8 qd[S8_NQ];
+    int er[S8_NQ];
 #pragma unroll
-    for (int k = 0; k < S8_NQ; ++k) qd[k] = quad8_desc<ROWKB>(role, gtid + k * GT, H, W, tiles_i, j0, col0);
+    for (int k = 0; k < S8_NQ; ++k) {
+        er[k] = ring_index(gtid + k * GT);
+        qd[k] = quad8_desc<ROWKB>(role, er[k], H, W, tiles_i, j0, col0);
+    }
     // (quads 1600..2047 do not exist: their descriptors are empty -- an out-of-range request, zeros into ring
     // slots nobody reads -- so that G production stays branch-free)
     const int g_step = 4 * W * CELLS * 4;                            // gradOut bytes per 4 map rows
@@ -196,7 +216,7 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     };
     auto g_put = [&](float* rb, int k, const f32x4& raw) {
         const f32x4 v = quad8_fix(raw, qd[k].info);
-        const int e = gtid + k * GT;
+        const int e = GCO ? er[k] : gtid + k * GT;
         if (!role) { reinterpret_cast<f32x4*>(rb)[e] = v; return; }
         // role 1: component lo2 = s of the quads of lanes (tpi*4 + c, gg), c = 0..3
         float* w = rb + (((e & ~63) + (lane & 0x3c)) << 2) + (lane & 3);

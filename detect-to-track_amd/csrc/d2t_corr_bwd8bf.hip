@@ -140,7 +140,7 @@ template <int role, int ABL = 0>   // ABL: ablation mask for timing experiments 
 __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, const float* __restrict__ gout,
                                              const float* __restrict__ fm0, const float* __restrict__ fm1,
                                              float* __restrict__ g0, float* __restrict__ g1,
-                                             int b, int tj, int C, int H, int W, int tiles_i)
+                                             int b, int tj, int yb, int C, int H, int W, int tiles_i)
 {
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,7 +155,7 @@ __device__ __forceinline__ void stripbf_body(unsigned char* __restrict__ ring, c
     const __amdgpu_buffer_rsrc_t rx = uniform_rsrc(gx, plane_bytes);
     const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(gb, (unsigned)HW * CELLS * 4u);
 
-    const int cw = blockIdx.y * BF_CH + wave * (BF_CT * 16);         // first channel of this wave's first c-tile
+    const int cw = yb * BF_CH + wave * (BF_CT * 16);         // first channel of this wave's first c-tile
     // S piece (block q, half h) at super-step 0, c-tile 0 (bytes): lane (channel n, lane group g).  Channels >= C lie
     // behind the buffer: zeros.  Rows >= H (last super-step) read the next plane or the range check's zeros: their G is 0.
     int sv[BF_NB][2];
@@ -388,10 +388,13 @@ k_corr_bwd_strip8bf(const float* __restrict__ gout, const float* __restrict__ fm
                     int B, int C, int H, int W, int tiles_i, int tiles_j)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];   // BF_LDS bytes
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // both roles of a batch item stay on one XCD: they share gradOut[b]
-    const int tj = bid % tiles_j, role = (bid / tiles_j) & 1, b = bid / (2 * tiles_j);
-    if (role) stripbf_body<1, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
-    else stripbf_body<0, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i);
+    // The hardware deals workgroups to the XCDs by their LINEAR id (x fastest, then y): the map is applied to that id and
+    // (strip, channel block, role, batch item) decoded from the result, as k_corr_bwd_strip8 does -- both roles of a batch
+    // item (they share gradOut[b]) and the strips of a channel block (they share rows of S) stay on one XCD.
+    const int nb = gridDim.y, lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * nb);
+    const int tj = lid % tiles_j, yb = (lid / tiles_j) % nb, role = (lid / (tiles_j * nb)) & 1, b = lid / (2 * tiles_j * nb);
+    if (role) stripbf_body<1, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, yb, C, H, W, tiles_i);
+    else stripbf_body<0, ABL>(ring, gout, fm0, fm1, g0, g1, b, tj, yb, C, H, W, tiles_i);
 }
 
 }  // namespace

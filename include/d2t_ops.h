@@ -71,13 +71,20 @@ const char* d2t_error_string(int code);
  *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)
  *   D2T_IMPL_MFMA    the tuned path, demanded: correlation returns D2T_EINVAL when its preconditions
  *                    (d_max = 8, stride 1, W >= 20) do not hold; the pooling ops fall back to generic */
-enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA_STRIP16 = 3, D2T_IMPL_BF16X3 = 4 };
+enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA_STRIP16 = 3, D2T_IMPL_BF16X3 = 4, D2T_IMPL_FAST = 5 };
 /*   D2T_IMPL_MFMA_STRIP16  as D2T_IMPL_MFMA, but the correlation backward always takes the 16-wave strip kernel
  *                          (the default before the 8-wave one existed): same-process A/B measurements
  *   D2T_IMPL_BF16X3        as D2T_IMPL_MFMA, but the correlation backward (reference layout, map at least 17 rows high)
  *                          runs on the bf16 matrix pipe with every f32 operand split into three bf16 pieces (six piece
  *                          products per product): as accurate as the f32 chain (<= 1e-5 of sum|terms|, deterministic), not
- *                          the default -- an experiment kept selectable */
+ *                          the default -- an experiment kept selectable
+ *   D2T_IMPL_FAST          as D2T_IMPL_AUTO, and the correlation FORWARD may re-associate its channel sum: small grids with
+ *                          many channels (the model's B = 1 pairs with 1024 / 2048 channels) split the channels of a level
+ *                          over several workgroups and add the partial sums in a fixed order -- deterministic, within 1e-5
+ *                          of the reference's single ascending-channel chain, NOT bit-identical to it (needs the workspace
+ *                          of d2t_corr_fwd*_workspace_bytes; without it the call runs as D2T_IMPL_AUTO).  Every other
+ *                          selector keeps the forward bit-identical to the reference: exactness is the default, speed the
+ *                          opt-in.  (B = 1, C = 2048, 38x75: 118 us exact, 63 us fast.) */
 
 /* ---------------- PointwiseCorrelation ---------------- */
 size_t d2t_corr_fwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size);
@@ -109,15 +116,16 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1,
  *   D2T_LAYOUT_CHANNEL_MAJOR  cell (ci,cj) of pixel (i,j) of item b at
  *                             out[l][b*batch_stride + (ci*(2d+1)+cj)*H*W + i*W + j]:
  *                             out[l] may point into a wider (channels,H,W) buffer
- * Values equal those of d2t_corr_fwd_f32 / d2t_corr_bwd_f32 on the same inputs (bit for bit where neither call
- * splits channels, see d2t_corr_fwd_levels_workspace_bytes).
+ * Values equal those of d2t_corr_fwd_f32 / d2t_corr_bwd_f32 on the same inputs (forward: bit for bit unless
+ * impl = D2T_IMPL_FAST splits channels, see d2t_corr_fwd_levels_workspace_bytes).
  * Arrays of pointers / channel counts are HOST arrays of n_levels entries.                      */
 enum { D2T_LAYOUT_REFERENCE = 0, D2T_LAYOUT_CHANNEL_MAJOR = 1 };
 
 /* Scratch that lets small-grid calls (the model's B = 1 pairs with 1024 / 2048 channels) split the channels of a level
  * over several workgroups and add the partial sums in a fixed order (deterministic; agrees with the unsplit result to
- * f32 rounding, not bit for bit).  Optional: with ws = NULL / too small, or impl = D2T_IMPL_MFMA, the unsplit kernels
- * run (bit-identical to the reference).  0 when the call would not split.  C: HOST array of n_levels entries. */
+ * f32 rounding, not bit for bit).  Only impl = D2T_IMPL_FAST uses it; with any other selector, or ws = NULL / too
+ * small, the unsplit kernels run (bit-identical to the reference).  0 when the call would not split under
+ * D2T_IMPL_FAST.  C: HOST array of n_levels entries. */
 size_t d2t_corr_fwd_levels_workspace_bytes(int n_levels, const int* C, int B, int H, int W, int d, int stride);
 
 int d2t_corr_fwd_levels_f32(int n_levels, const float* const* fm0, const float* const* fm1, float* const* out,
@@ -187,6 +195,8 @@ int d2t_corr_mask(uint8_t* mask, int H, int W, int d, int stride, d2t_stream_t s
  * confidences (ties: lower anchor index first); greedy NMS in descending confidence, a kept box removes every later
  * box with IoU > iou_thresh.  (`ml_utils` is not vendored with the reference: parity for the filters is unpinned.)
  *   anchors, offsets (A,4); confs (A): device, float32; boxes are (centre_i, centre_j, height, width) fractions.
+ *   anchors, offsets, out_boxes and ws are read / written as 16-byte vectors: they must be 16-byte aligned
+ *   (D2T_EINVAL otherwise); confs, out_conf, out_idx and out_count need 4-byte alignment only.
  *   out_boxes (max_dets,4), out_conf (max_dets), out_idx (max_dets, anchor index or -1), out_count (1): device.
  *   Survivors come first, in descending confidence; the rest of the lists is padding (zero boxes, index -1), so the
  *   caller can keep static shapes and never reads the count back.  max_dets <= 4096.                            */

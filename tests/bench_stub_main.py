@@ -4,7 +4,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port P tests/bench_stub_main.py --gpus 2 --steps K --warmup W
 
-It runs bench.run() -- the real rank skeleton: WORLD_SIZE check, process-group init, setup, warmup,
+(or bare, `python tests/bench_stub_main.py --gpus 2 ...`: bench.main() then launches the two ranks itself).
+It runs bench.main() / bench.run() -- the real rank skeleton: WORLD_SIZE check, process-group init, setup, warmup,
 barrier, K timed steps, barrier, MAX over ranks, one JSON line on rank 0, teardown -- with the two
 op calls replaced by a sleep whose length depends on the rank, and gloo instead of RCCL.  The HIP
 library is not loaded; nothing here is reachable from bench.py itself.
@@ -71,11 +72,20 @@ class CpuStub:
 
 
 if __name__ == "__main__":
-    a = bench.parse_args()
-    a.no_cpu_baseline = True
-    stub = CpuStub()
-    bench.run(a, stub)
-    settle = min(3 * a.steps, bench.SETTLE_STEPS)                  # bounded untimed steps before the timed region
+    # The same entry as `python3 bench.py ...`: under torch.distributed.run this process is a rank; launched bare with
+    # --gpus N > 1 bench.main() starts the N ranks of THIS script itself (bench.launch_ranks) and exits with their code.
+    made = []
+
+    def factory():
+        made.append(CpuStub())
+        return made[0]
+
+    argv = sys.argv[1:] + ["--no-cpu-baseline"]
+    info = bench.main(argv, device_factory=factory, script=Path(__file__).resolve())
+    a, stub = bench.parse_args(argv), made[0]
+    settle = info["settle_steps"]                                # untimed clock-settling steps (bounded by wall time, in batches)
+    assert settle % bench.SETTLE_BATCH == 0 and (settle > 0) == (a.settle_ms > 0)
     n = stub.n_sets + a.warmup + settle + a.steps * (4 if a.graph else 2)   # + the timed steps and the event pass (+ 2 graph replays of them)
     assert stub.calls == {"fwd": n, "bwd": n}, stub.calls
+    assert info["ranks_seen"] == a.gpus
     print(f"stub rank {stub.rank} done", file=sys.stderr)

@@ -15,6 +15,7 @@ DEV = "cuda:0"
 
 
 MFMA = 2                                                                     # D2T_IMPL_MFMA: tuned kernels, never channel-split
+FAST = 5                                                                     # D2T_IMPL_FAST: the forward may split channels over workgroups
 
 
 def _splits(Cs, B, H, W, d, s):
@@ -54,14 +55,15 @@ def test_levels_forward_backward_equal_unfused(case):
     want = _unfused(fm0s, fm1s, d, s, MFMA if d == 8 and s == 1 and W >= 20 else 0)   # unsplit kernels: the reference's chain, bit for bit
     got = _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s)
     assert got.shape == want.shape
+    assert torch.equal(got, want)                                             # default dispatch: the reference's chain, bit for bit
     if _splits(Cs, B, H, W, d, s):
-        # channels split over workgroups, partial sums added in a fixed order: same terms, other association
-        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
-        assert torch.equal(got, _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s))          # deterministic
-        assert torch.equal(_ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s, impl=MFMA), want)   # opt out: bit-exact
-        want = got
+        # opt-in (D2T_IMPL_FAST): channels split over workgroups, partial sums added in a fixed order -- same terms, other association
+        fast = _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s, impl=FAST)
+        torch.testing.assert_close(fast, want, rtol=1e-5, atol=1e-5)
+        assert not torch.equal(fast, want) or max(Cs) < 640                   # it really took the other path
+        assert torch.equal(fast, _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s, impl=FAST))   # deterministic
     else:
-        assert torch.equal(got, want)
+        assert torch.equal(_ext.pointwise_correlation_levels_forward(fm0s, fm1s, d, s, impl=FAST), want)
     # into the middle of a wider buffer (a torch.cat target), neighbours untouched
     pad0, pad1 = 5, 3
     buf = torch.full((B, pad0 + len(Cs) * cells + pad1, H, W), -7.0, device=DEV)

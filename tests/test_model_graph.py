@@ -86,6 +86,7 @@ def test_config4_step_at_size_ops_match_reference_kernels(ref_modules, oracle):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = DetectTrackModule("resnet50", 3, 15, 30, 7, 8, 7).to(dev).train()
+    model.c_tracker.fast_forward = True        # as bench_model.py runs it: D2T_IMPL_FAST, the 1024 / 2048-channel levels split channels
     H, W, B, R, T = 608, 1008, 2, 300, 8
     fh, fw = 38, 63
     anchors = build_anchors((fh, fw), [0.001, 0.004, 0.016, 0.064, 0.256], [0.5, 1.0, 2.0])

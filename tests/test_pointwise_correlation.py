@@ -80,10 +80,11 @@ CASES = [  # (B, C, H, W, d, s)
 
 @pytest.mark.parametrize("case", [(1, 1040, 38, 75), (2, 800, 21, 44), (1, 2048, 38, 75)], ids=str)
 def test_channel_split_forward(case, oracle):
-    """Small grids with many channels (the model's B = 1 pairs, correlation_tracker.py:68-70) split the channels of a
-    call over several workgroups and add the partial sums in a fixed order.  Same terms as the reference's chain
-    (pointwise_correlation_cuda.cu:105-107), other association: within 1e-5 of the oracle, deterministic, structural
-    zeros exact; D2T_IMPL_MFMA opts out and is bit-identical to the oracle."""
+    """Opt-in (impl = D2T_IMPL_FAST): small grids with many channels (the model's B = 1 pairs, correlation_tracker.py:68-70)
+    split the channels of a call over several workgroups and add the partial sums in a fixed order.  Same terms as the
+    reference's chain (pointwise_correlation_cuda.cu:105-107), other association: within 1e-5 of the oracle,
+    deterministic, structural zeros exact.  The DEFAULT dispatch (and D2T_IMPL_MFMA) never splits: bit-identical to the
+    oracle."""
     import ctypes
     from detect_to_track.models import _ext, _native
     B, C, H, W = case
@@ -91,13 +92,29 @@ def test_channel_split_forward(case, oracle):
     rng = np.random.default_rng(C + H)
     fm0, fm1 = rng.random((B, C, H, W), dtype=np.float32), rng.standard_normal((B, C, H, W)).astype(np.float32)
     want = oracle.corr_fwd(fm0, fm1, 8, 1)
-    got = _ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1)
+    got = _ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1, _native.IMPL_FAST)
     # sum |terms| <= sum |fm0||fm1| ~ 0.4 C: 1e-5 of the magnitude scale of an element
     np.testing.assert_allclose(_n(got), want, rtol=1e-5, atol=1e-5 * 0.4 * C)
+    assert not np.array_equal(_n(got), want), "D2T_IMPL_FAST did not take the split path"
     mask = oracle.corr_mask(H, W, 8, 1).astype(bool)
     assert not _n(got)[:, ~mask].any()                                 # structural zeros are exact zeros
-    assert torch.equal(got, _ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1))
+    assert torch.equal(got, _ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1, _native.IMPL_FAST))
+    np.testing.assert_array_equal(_n(_ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1)), want)      # default: exact
     np.testing.assert_array_equal(_n(_ext.pointwise_correlation_forward(_t(fm0), _t(fm1), 8, 1, 2)), want)
+
+
+@pytest.mark.parametrize("case", [(1, 1024, 38, 75), (1, 2048, 38, 75), (2, 800, 21, 44)], ids=str)
+def test_channel_split_forward_live_reference(case, ref_modules):
+    """The same opt-in path against the reference's own kernels on U[0,1) data (post-ReLU features are non-negative):
+    plain rtol 1e-5, no magnitude-scaled atol; the default dispatch at these shapes bit for bit."""
+    from detect_to_track.models import _ext, _native
+    ref_corr = ref_modules[0]
+    B, C, H, W = case
+    torch.manual_seed(C)
+    fm0, fm1 = torch.rand(B, C, H, W, device=DEV), torch.rand(B, C, H, W, device=DEV)
+    ref = ref_corr.pointwise_correlation_forward(fm0, fm1, 8, 1)
+    assert torch.equal(_ext.pointwise_correlation_forward(fm0, fm1, 8, 1), ref)
+    torch.testing.assert_close(_ext.pointwise_correlation_forward(fm0, fm1, 8, 1, _native.IMPL_FAST), ref, rtol=1e-5, atol=0.0)
 
 
 @pytest.mark.parametrize("impl", [0, 1], ids=["auto", "generic"])

@@ -58,16 +58,60 @@ def test_matches_numpy_pipeline(case):
     assert not got_boxes[n:].any() and not conf_d.cpu().numpy()[n:].any()
     all_boxes = want_boxes.copy()
     all_boxes[idx[:n]] = got_boxes[:n]                                 # the device's values where it reported them
-    keep, _ = oracle_regions.region_filter(confs, all_boxes, thr, k, iou)
-    if not np.array_equal(keep, idx[:n]):                              # a box the device dropped may differ in its last bit: retry with
-        sel = np.nonzero(confs > np.float32(thr))[0]                   # the candidates' device values is not possible (not exported) --
-        order = sel[np.argsort(-confs[sel], kind="stable")][:k]        # so demand agreement only when every IoU decision has a margin
-        b = want_boxes[order]
-        margin = min((np.abs(oracle_regions.iou_one_to_many(b[i], b[i + 1:]) - iou).min() if i + 1 < len(b) else 1.0) for i in range(len(b)))
-        assert margin < 1e-6, "kept sets differ although no IoU sits at the threshold"
-    else:
-        np.testing.assert_array_equal(conf_d.cpu().numpy()[:n], confs[keep])
-        assert n == len(keep) and (np.diff(confs[keep]) <= 0).all()
+    _check_every_nms_decision(confs, all_boxes, thr, k, iou, idx[:n], conf_d.cpu().numpy()[:n])
+
+
+def _check_every_nms_decision(confs, boxes, thr, k, iou, dev_keep, dev_conf, tol=1e-6, max_marginal=4):
+    """Replays the greedy NMS candidate by candidate FOLLOWING the device's decisions and checks each one: candidate c
+    (in descending confidence, ties by anchor index) must be kept iff no earlier kept box has IoU > iou with it.  The only
+    excuse is a decision whose own deciding IoU lies within `tol` of the threshold (the boxes of candidates the device
+    dropped are not exported, and expf differs from numpy's exp in the last bit) -- and at most `max_marginal` of them.
+    A wrong drop, a wrong keep, a wrong order or a wrong top-k cut anywhere else fails."""
+    sel = np.nonzero(confs > np.float32(thr))[0]
+    order = sel[np.argsort(-confs[sel], kind="stable")][:k]            # ConfidenceFilter + MaxDetFilter (ties: lower index first)
+    dev_keep = np.asarray(dev_keep, dtype=np.int64)
+    assert np.isin(dev_keep, order).all(), "the device kept a box that is not among the top-k candidates above the threshold"
+    pos = {int(a): p for p, a in enumerate(order)}
+    assert (np.diff([pos[int(a)] for a in dev_keep]) > 0).all(), "kept boxes are not in descending-confidence order"
+    np.testing.assert_array_equal(dev_conf, confs[dev_keep])
+    kept_set = set(int(a) for a in dev_keep)
+    kept_boxes = np.empty((0, 4), np.float32)
+    marginal = 0
+    for a in order:
+        b = boxes[a]
+        ious = oracle_regions.iou_one_to_many(b, kept_boxes) if len(kept_boxes) else np.zeros(0, np.float32)
+        top = float(ious.max()) if len(ious) else 0.0
+        want_keep = not (ious > np.float32(iou)).any()
+        got_keep = int(a) in kept_set
+        if want_keep != got_keep:
+            assert abs(top - iou) < tol, (f"candidate {int(a)}: device {'kept' if got_keep else 'dropped'} it, max IoU with the kept boxes "
+                                          f"before it is {top:.7f} against a threshold of {iou}")
+            marginal += 1
+        if got_keep:
+            kept_boxes = np.concatenate([kept_boxes, b[None]])
+    assert marginal <= max_marginal, f"{marginal} decisions sat within {tol} of the threshold: not credible"
+
+
+def test_nms_decision_checker_bites():
+    """The checker itself (CPU): it accepts the numpy pipeline's own result and rejects a list with one box wrongly dropped,
+    one wrongly kept, two swapped, or one from below the top-k cut."""
+    rng = np.random.default_rng(3)
+    anchors = _anchors(20, 20, rng)
+    A = len(anchors)
+    offsets = (rng.standard_normal((A, 4)) * 0.5 * [0.5, 0.5, 0.3, 0.3]).astype(np.float32)
+    confs = rng.random(A).astype(np.float32)
+    boxes = oracle_regions.box_decode(anchors, offsets)
+    keep, _ = oracle_regions.region_filter(confs, boxes, 0.3, 300, 0.5)
+    _check_every_nms_decision(confs, boxes, 0.3, 300, 0.5, keep, confs[keep])
+    sel = np.nonzero(confs > np.float32(0.3))[0]
+    order = sel[np.argsort(-confs[sel], kind="stable")]
+    dropped = [a for a in order[:300] if a not in set(keep.tolist())]
+    wrong = {"drop": np.delete(keep, 7), "keep": np.sort(np.append(keep, dropped[0]))[::1], "swap": keep[[1, 0] + list(range(2, len(keep)))],
+             "below_cut": np.append(keep, order[300])}
+    wrong["keep"] = np.asarray(sorted(wrong["keep"].tolist(), key=lambda a: list(order).index(a)))
+    for name, bad in wrong.items():
+        with pytest.raises(AssertionError):
+            _check_every_nms_decision(confs, boxes, 0.3, 300, 0.5, bad, confs[bad])
 
 
 @pytest.mark.gpu
@@ -87,3 +131,8 @@ def test_degenerate_inputs():
     assert int(n) > 0 and (kept % 3 != 0).all() and (np.diff(kept) > 0).all()       # equal confidences: anchor order
     with pytest.raises(RuntimeError):
         _ext.region_filter(a, off, conf, 0.3, 5000, 0.5)                              # max_dets > 4096
+    # boxes move as 16-byte vectors: a pointer that is only 4-byte aligned is refused (D2T_EINVAL), not dereferenced
+    skew = torch.zeros(4 * A + 1, device=DEV)[1:].view(A, 4)
+    assert skew.data_ptr() % 16 == 4 and skew.is_contiguous()
+    with pytest.raises(RuntimeError):
+        _ext.region_filter(skew, off, conf, 0.3, 32, 0.5)

@@ -101,6 +101,7 @@ def test_bench_rank_skeleton_under_torchrun():
     import bench
     assert d["metric"] == bench.METRIC and d["n_gpus"] == 2 and d["steps"] == K and d["warmup"] == W
     assert d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "shard2"
+    assert d["ranks_seen"] == 2 and d["settle_ms"] >= 100.0
     # the slow rank (rank 1 sleeps 2x) sets the time: MAX over ranks, not rank 0's own clock
     assert d["ms_per_step"] >= 2 * (2 + 3) * 0.95, d["ms_per_step"]
     vox = bench.corr_counts(**bench.WORKLOADS["corr_B8_C256_38x63_d8"])["vox"]
@@ -114,9 +115,45 @@ def test_bench_rank_skeleton_under_torchrun():
     assert p.stderr.count("stub rank") == 2
 
 
-def test_bench_single_rank_refuses_mismatched_world():
+@pytest.mark.timeout(300)
+def test_bench_bare_form_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` the way the driver launches N = 1 -- no torch.distributed.run in front, no
+    WORLD_SIZE in the environment: the GPU-free parent (bench.main -> bench.launch_ranks) starts the two ranks as a child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ...` and hands back their exit
+    code; rank 0's line is the only JSON line.  Device layer = this test's stub, as above."""
+    K, W = 3, 1
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "tests" / "bench_stub_main.py"), "--gpus", "2", "--steps", str(K), "--warmup", str(W),
+           "--settle-ms", "30"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == K and d["config"]["global_batch"] == 16
+    assert d["settle_steps"] >= 25 and d["settle_ms"] >= 30.0
+    assert p.stderr.count("stub rank") == 2                 # both ranks ran to the end
+
+
+def test_bench_parent_never_touches_the_gpu():
+    """The bare-form parent must start the ranks BEFORE anything imports torch or initialises HIP (a process that has
+    touched the GPU must not spawn / be replaced by ranks on this pool): bench.py imports torch only inside functions
+    the parent does not call, and a failing child's exit code is handed back."""
+    src = (ROOT / "bench.py").read_text()
+    head = src.split("def corr_counts")[0]
+    assert "import torch" not in head                       # module level: no torch
     sys.path.insert(0, str(ROOT))
     import bench
+    code = bench.launch_ranks(ROOT / "tests" / "no_such_script.py", [], 2)
+    assert code != 0
+
+
+def test_bench_rank_refuses_mismatched_world(monkeypatch):
+    sys.path.insert(0, str(ROOT))
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1")
     a = bench.parse_args(["--gpus", "2"])
     with pytest.raises(SystemExit):
-        bench.run(a, object())                              # WORLD_SIZE is 1 here: refused before any device call
+        bench.run(a, object())                              # a rank whose WORLD_SIZE disagrees with --gpus: refused before any device call
