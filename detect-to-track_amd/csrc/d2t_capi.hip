@@ -40,7 +40,12 @@ int check_pool(const void* fm, const void* rois, const void* out, int R, int C, 
 }
 
 // D2T_IMPL_MFMA .. D2T_IMPL_BF16X3 demand the tuned kernels (an unsupported shape is an error); AUTO / FAST fall back
-inline bool demands_tuned(int impl) { return impl >= D2T_IMPL_MFMA && impl <= D2T_IMPL_BF16X3; }
+inline bool demands_tuned(int impl) { return impl >= D2T_IMPL_MFMA && impl != D2T_IMPL_FAST; }
+// backward kernel choice of the tuned path: 0 by grid size, 1 the 16-wave strip kernel, 3 bf16x3, 4 strips 8 pixels wide, 5 strips 4 pixels wide
+inline int bwd_variant_of(int impl)
+{
+    return impl == D2T_IMPL_MFMA_STRIP16 ? 1 : impl == D2T_IMPL_BF16X3 ? 3 : impl == D2T_IMPL_MFMA_WIDE8 ? 4 : impl == D2T_IMPL_MFMA_STRIP4 ? 5 : 0;
+}
 
 inline size_t bins_bytes(int R, int k) { return align_up((size_t)R * k * k * 4 * sizeof(int32_t), 256); }
 
@@ -74,7 +79,7 @@ size_t d2t_corr_bwd_workspace_bytes(int B, int C, int H, int W, int d, int strid
 int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int stride,
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::corr_fwd_supported(B, C, H, W, d, stride)) {
@@ -90,7 +95,7 @@ int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int 
 int d2t_corr_fwd_f64(const double* fm0, const double* fm1, double* out, int B, int C, int H, int W, int d, int stride,
                      void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (demands_tuned(impl)) return D2T_EINVAL;
@@ -101,14 +106,14 @@ int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, floa
                      int B, int C, int H, int W, int d, int stride,
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
     if (impl != D2T_IMPL_GENERIC && tuned::corr_bwd_supported(B, C, H, W, d, stride)) {
         if (ws_bytes < tuned::corr_bwd_ws_bytes(B, C, H, W, d, stride)) return D2T_EWS;
         return tuned::corr_bwd_f32(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, ws, as_stream(stream),
-                                   impl == D2T_IMPL_MFMA_STRIP16 ? 1 : (impl == D2T_IMPL_BF16X3 ? 3 : 0));
+                                   bwd_variant_of(impl));
     }
     if (demands_tuned(impl)) return D2T_EINVAL;
     return corr_bwd_generic<float>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
@@ -118,7 +123,7 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1, d
                      int B, int C, int H, int W, int d, int stride,
                      void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
@@ -154,7 +159,7 @@ int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* 
                             int B, int H, int W, int d, int stride, int layout, long long bstride,
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)out, C, B, H, W, d, stride, layout, bstride);
     if (rc != D2T_OK) return rc;
     const int cells = (2 * d + 1) * (2 * d + 1), HW = H * W;
@@ -179,7 +184,7 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
                             int B, int H, int W, int d, int stride, int layout, long long bstride,
                             void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)gout, C, B, H, W, d, stride, layout, bstride);
     if (rc != D2T_OK) return rc;
     if (!gfm0 || !gfm1) return D2T_EINVAL;
@@ -191,7 +196,7 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
     bool tuned_ok = impl != D2T_IMPL_GENERIC;
     for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_bwd_supported(B, C[l], H, W, d, stride);
     if (tuned_ok) return tuned::corr_bwd_levels_f32(n, gout, fm0, fm1, gfm0, gfm1, C, B, H, W, lay, as_stream(stream),
-                                                    impl == D2T_IMPL_MFMA_STRIP16 ? 1 : (impl == D2T_IMPL_BF16X3 ? 3 : 0));
+                                                    bwd_variant_of(impl));
     if (demands_tuned(impl)) return D2T_EINVAL;
     for (int l = 0; l < n; ++l) {
         rc = corr_bwd_generic<float>(gout[l], fm0[l], fm1[l], gfm0[l], gfm1[l], B, C[l], H, W, d, stride, as_stream(stream),
@@ -216,7 +221,7 @@ size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int el
 int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_pool(fm, rois, out, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     // The tuned forward builds a summed-area table of every channel (the whole map is read once): for
@@ -233,7 +238,7 @@ int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, i
 int d2t_roipool_fwd_f64(const double* fm, const double* rois, double* out, int R, int C, int H, int W, int k,
                         void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_pool(fm, rois, out, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     return roipool_fwd_generic<double>(fm, rois, out, R, C, H, W, k, as_stream(stream));
@@ -242,7 +247,7 @@ int d2t_roipool_fwd_f64(const double* fm, const double* rois, double* out, int R
 int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::roipool_bwd_supported(R, C, H, W, k)) {
@@ -256,7 +261,7 @@ int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R,
 int d2t_roipool_bwd_f64(const double* gout, const double* rois, double* gin, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
@@ -288,7 +293,7 @@ static int check_ps(const void* fm, const void* rois, const void* out, int R, in
 int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_ps(fm, rois, out, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && R > 0 && tuned::psroipool_fwd_supported(R, nT, H, W, k)) {
@@ -302,7 +307,7 @@ int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R,
 int d2t_psroipool_fwd_f64(const double* fm, const double* rois, double* out, int R, int nT, int H, int W, int k,
                           void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_ps(fm, rois, out, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     return psroipool_fwd_generic<double>(fm, rois, out, R, nT, H, W, k, as_stream(stream));
@@ -311,7 +316,7 @@ int d2t_psroipool_fwd_f64(const double* fm, const double* rois, double* out, int
 int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::psroipool_bwd_supported(R, nT, H, W, k)) {
@@ -325,7 +330,7 @@ int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int 
 int d2t_psroipool_bwd_f64(const double* gout, const double* rois, double* gin, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_FAST) return D2T_EINVAL;
+    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;

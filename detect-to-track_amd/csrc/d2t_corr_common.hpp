@@ -108,6 +108,12 @@ bool corr_bwd8_supported(int B, int C, int H, int W, int ps, int cs);
 int  corr_bwd8_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
                    int B, int C, int H, int W, hipStream_t st, int variant = 0);
 
+// d2t_corr_bwd8w.hip
+bool corr_bwd8w_supported(int B, int C, int H, int W, int ps, int cs);
+long long corr_bwd8w_workgroups(int B, int C, int W);
+int  corr_bwd8w_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
+                    int B, int C, int H, int W, hipStream_t st);
+
 // d2t_corr_bwd8bf.hip
 bool corr_bwd8bf_supported(int B, int C, int H, int W, int ps, int cs);
 int  corr_bwd8bf_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,

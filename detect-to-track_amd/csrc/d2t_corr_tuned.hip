@@ -1376,10 +1376,21 @@ bool corr_bwd_supported(int B, int C, int H, int W, int d, int s)
 
 size_t corr_bwd_ws_bytes(int, int, int, int, int, int) { return 0; }
 
+#ifndef D2T_BWD_WIDE_DEFAULT
+#define D2T_BWD_WIDE_DEFAULT 0
+#endif
+
 // nl problems of one spatial shape.  Reference layout: every level is launched by itself with the 8-wave kernel of
 // d2t_corr_bwd8.hip (channel blocks sized to the grid).  Channel-major layout, maps shorter than 17 rows, or on request:
 // a level whose 256-channel grid fills at least 100 CUs takes k_corr_bwd_strip, the remaining levels share ONE launch
 // of the 4-wave kernel, heaviest first.
+// Default choice between the two 8-wave kernels (both reference layout): strips 8 pixels wide need their grid
+// (2 B ceil(W/8) ceil(C/128) workgroups) to fill the chip; the 4-pixel kernel sizes its channel blocks to any grid.
+static bool corr_bwd_prefers_wide(int B, int C, int W)
+{
+    return D2T_BWD_WIDE_DEFAULT && corr_bwd8w_workgroups(B, C, W) >= 224;
+}
+
 int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
                         float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
                         int bwd_variant)
@@ -1390,6 +1401,10 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
         const long long wide = 2LL * B * tiles_j * ((C[l] + ST_CH - 1) / ST_CH);   // workgroups of 16 waves x 16 channels
         if (bwd_variant == 3 && corr_bwd8bf_supported(B, C[l], H, W, lay.ps, lay.cs)) {  // bf16 matrix pipe, operands split in three
             const int rc = corr_bwd8bf_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st);
+            if (rc != D2T_OK) return rc;
+        } else if (bwd_variant != 1 && bwd_variant != 5 && corr_bwd8w_supported(B, C[l], H, W, lay.ps, lay.cs) &&
+                   (bwd_variant == 4 || corr_bwd_prefers_wide(B, C[l], W))) {            // strips 8 pixels wide x 128 channels
+            const int rc = corr_bwd8w_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st);
             if (rc != D2T_OK) return rc;
         } else if (bwd_variant != 1 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {   // any grid: the kernel cuts the channels to fit it
             const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st, bwd_variant == 2 ? 1 : 0);

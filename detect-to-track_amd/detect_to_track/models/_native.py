@@ -21,7 +21,7 @@ _HERE = Path(__file__).resolve().parent
 _LIB_ENV = "D2T_OPS_LIBRARY"
 _DEFAULT = _HERE.parent.parent / "lib" / "libd2t_ops.so"
 
-IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_STRIP16, IMPL_BF16X3, IMPL_FAST = 0, 1, 2, 3, 4, 5
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_STRIP16, IMPL_BF16X3, IMPL_FAST, IMPL_MFMA_WIDE8, IMPL_MFMA_STRIP4 = range(8)
 
 
 def _locate() -> Path:

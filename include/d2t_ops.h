@@ -71,7 +71,8 @@ const char* d2t_error_string(int code);
  *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)
  *   D2T_IMPL_MFMA    the tuned path, demanded: correlation returns D2T_EINVAL when its preconditions
  *                    (d_max = 8, stride 1, W >= 20) do not hold; the pooling ops fall back to generic */
-enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA_STRIP16 = 3, D2T_IMPL_BF16X3 = 4, D2T_IMPL_FAST = 5 };
+enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA_STRIP16 = 3, D2T_IMPL_BF16X3 = 4, D2T_IMPL_FAST = 5,
+       D2T_IMPL_MFMA_WIDE8 = 6, D2T_IMPL_MFMA_STRIP4 = 7 };
 /*   D2T_IMPL_MFMA_STRIP16  as D2T_IMPL_MFMA, but the correlation backward always takes the 16-wave strip kernel
  *                          (the default before the 8-wave one existed): same-process A/B measurements
  *   D2T_IMPL_BF16X3        as D2T_IMPL_MFMA, but the correlation backward (reference layout, map at least 17 rows high)
@@ -84,7 +85,11 @@ enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA
  *                          of the reference's single ascending-channel chain, NOT bit-identical to it (needs the workspace
  *                          of d2t_corr_fwd*_workspace_bytes; without it the call runs as D2T_IMPL_AUTO).  Every other
  *                          selector keeps the forward bit-identical to the reference: exactness is the default, speed the
- *                          opt-in.  (B = 1, C = 2048, 38x75: 118 us exact, 63 us fast.) */
+ *                          opt-in.  (B = 1, C = 2048, 38x75: 118 us exact, 63 us fast.)
+ *   D2T_IMPL_MFMA_WIDE8 /  as D2T_IMPL_MFMA, but the correlation backward (reference layout, map at least 17 rows high) always
+ *   D2T_IMPL_MFMA_STRIP4   takes the kernel on strips 8 pixels wide x 128 channels (csrc/d2t_corr_bwd8w.hip) / on strips 4 pixels
+ *                          wide x up to 256 channels (csrc/d2t_corr_bwd8.hip): D2T_IMPL_AUTO picks between them by grid size;
+ *                          these two exist for same-process A/B measurements and tests of either kernel */
 
 /* ---------------- PointwiseCorrelation ---------------- */
 size_t d2t_corr_fwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size);

@@ -271,6 +271,68 @@ def test_bf16x3_backward_nonfinite_and_huge_inputs(oracle):
         torch.testing.assert_close(got[fin], want[fin], rtol=2e-5, atol=2e-3)   # elements next to the 3.4e38 values are ~1e37; the rest ~50
 
 
+WIDE8, STRIP4 = 6, 7        # D2T_IMPL_MFMA_WIDE8 / D2T_IMPL_MFMA_STRIP4: the two 8-wave backward kernels, demanded
+
+
+@pytest.mark.parametrize("impl", [WIDE8, STRIP4], ids=["wide8", "strip4"])
+@pytest.mark.parametrize("case", [(1, 32, 17, 24), (2, 130, 21, 30), (1, 128, 38, 63), (3, 40, 19, 75), (1, 16, 40, 21),
+                                  (2, 200, 23, 64), (1, 300, 38, 20), (1, 7, 17, 25)], ids=str)
+def test_strip_backward_kernels_match_oracle(case, impl, oracle):
+    """Both 8-wave backward kernels, each demanded (no dispatch by grid size): strips 8 pixels wide x 128 channels
+    (d2t_corr_bwd8w.hip: the window is not clamped to the map -- widths that are no multiple of 8 or narrower than one
+    strip window of 24 columns, channel counts that are no multiple of 128, heights that are no multiple of 4) and strips 4 pixels wide
+    (d2t_corr_bwd8.hip).  Signed data against the yardstick with the reference's f32 terms added in double
+    (pointwise_correlation_cuda.cu:154-171): 1e-5 of the sum of |terms|; deterministic."""
+    from detect_to_track.models import _ext
+    B, C, H, W = case
+    rng = np.random.default_rng(B * 1000 + C + W)
+    fm0, fm1 = rng.standard_normal((B, C, H, W)).astype(np.float32), rng.standard_normal((B, C, H, W)).astype(np.float32)
+    gout = rng.standard_normal((B, H, W, 17, 17)).astype(np.float32)
+    g0, g1 = _ext.pointwise_correlation_backward(_t(gout), _t(fm0), _t(fm1), 8, 1, impl)
+    (w0, w1), (m0, m1) = oracle.corr_bwd_acc64(gout, fm0, fm1, 8, 1)
+    oracle.assert_within_contract(_n(g0), w0, m0, 1e-5, "gradFM0")
+    oracle.assert_within_contract(_n(g1), w1, m1, 1e-5, "gradFM1")
+    h0, h1 = _ext.pointwise_correlation_backward(_t(gout), _t(fm0), _t(fm1), 8, 1, impl)
+    assert torch.equal(g0, h0) and torch.equal(g1, h1)
+
+
+@pytest.mark.parametrize("impl", [WIDE8, STRIP4], ids=["wide8", "strip4"])
+@pytest.mark.parametrize("case", [(8, 256, 38, 63), (2, 512, 38, 75), (1, 260, 21, 30)], ids=str)
+def test_strip_backward_kernels_match_live_reference(case, impl, ref_modules):
+    """Either kernel against the reference's own kernels on the same GPU, same inputs (the headline shape included)."""
+    from detect_to_track.models import _ext
+    ref_corr = ref_modules[0]
+    B, C, H, W = case
+    torch.manual_seed(4321)
+    fm0, fm1 = torch.rand(B, C, H, W, device=DEV), torch.rand(B, C, H, W, device=DEV)
+    gout = torch.rand(B, H, W, 17, 17, device=DEV)
+    g0, g1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, impl)
+    r0, r1 = ref_corr.pointwise_correlation_backward(gout, fm0, fm1, 8, 1)
+    torch.testing.assert_close(g0, r0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, r1, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("impl", [WIDE8, STRIP4], ids=["wide8", "strip4"])
+def test_strip_backward_kernels_nonfinite(impl):
+    """Inf / NaN in the maps and in gradOut -- also right at the map's left and right borders, where the unclamped window of
+    the 8-pixel kernel multiplies slots outside the map by G = 0: pattern and finite values of the reference-order kernels."""
+    from detect_to_track.models import _ext
+    B, C, H, W = 2, 40, 21, 29
+    torch.manual_seed(5)
+    fm0, fm1 = torch.rand(B, C, H, W, device=DEV), torch.rand(B, C, H, W, device=DEV)
+    gout = torch.rand(B, H, W, 17, 17, device=DEV)
+    fm1[0, 3, 5, 7] = float("inf"); fm0[1, 0, 9, 20] = float("nan"); gout[0, 6, 6, 3, 4] = float("-inf")
+    fm1[1, 9, 4, W - 1] = float("nan"); fm0[0, 2, 11, 0] = float("inf"); fm1[0, 0, 0, 0] = float("nan"); fm0[1, C - 1, H - 1, W - 1] = float("-inf")
+    gout[1, 7, 9, 16, 16] = float("nan")          # a cell the reference never reads
+    g0, g1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, impl)
+    r0, r1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, 8, 1, 1)
+    for got, want in ((g0, r0), (g1, r1)):
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        assert torch.equal(torch.isposinf(got), torch.isposinf(want)) and torch.equal(torch.isneginf(got), torch.isneginf(want))
+        fin = torch.isfinite(want)
+        torch.testing.assert_close(got[fin], want[fin], rtol=1e-5, atol=1e-5)
+
+
 def test_north_star_shape_properties():
     """B=8 C=256 38x63 d=8 (BASELINE.json metric shape): size-independent properties."""
     from detect_to_track.models import _ext
