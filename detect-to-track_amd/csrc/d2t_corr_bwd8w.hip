@@ -22,7 +22,8 @@
 // for one (centre pixel, cell row) are 32 consecutive bytes).
 // The strip window is NOT clamped to the map: slot columns left of column 0 / right of column W-1 exist in the
 // enumeration with G = 0 (their S operand is whatever lies there -- the neighbouring row, or the range check's
-// zeros); a non-finite value there is caught by the same repair path as any other (d2t_corr_common.hpp).
+// zeros); a non-finite value there is caught by the same repair path as any other (d2t_corr_common.hpp).  A piece
+// that straddles the END of the last channel's last row keeps its in-range dwords (per-dword range check).
 #include "d2t_corr_common.hpp"
 #include <type_traits>
 
@@ -30,6 +31,12 @@ namespace d2t { namespace tuned {
 
 namespace {
 
+#ifndef W8_LOOP
+#define W8_LOOP 0
+#endif
+#ifndef W8_ABL
+#define W8_ABL 0      // timing ablations (lab builds only, results are wrong): 1 no G loads, 2 no ring writes, 4 no tile stores, 8 no S reloads, 16 no fragment reads
+#endif
 constexpr int W8_CH = 128;                          // channels per workgroup: 8 waves x 1 c-tile
 constexpr int W8_KB = 6;                            // k-blocks per super-step (see above)
 constexpr int W8_FB = 4 * 2 * NACT + 2 * NACT;      // 50 fragment blocks (64 quads = 1 KB each) per super-step
@@ -41,6 +48,12 @@ constexpr int W8_LDS = 2 * W8_RING * 4;             // 114,688 bytes
 constexpr int W8_OOR = 0x7ffffff0;                  // byte offset that every buffer range check rejects
 
 struct Quad8w { int off, info; };
+
+// Inside its 64-quad fragment block the quad of lane l = (gg, pixel) of every k-block sits at position l ^ (gg & 3): the
+// reader's ds_read_b128 stays conflict-free (an XOR below 4 permutes inside aligned groups of four quads), while the
+// producer of role 0, whose consecutive lanes write the consecutive pieces (q, gg) of ONE pixel, spreads over four bank
+// groups instead of hitting one eight times (SQ_LDS_BANK_CONFLICT was 53 % of SQ_LDS_IDX_ACTIVE without it).
+__host__ __device__ constexpr int w8_swz(int gg) { return gg & 3; }
 
 // fragment block of (k-block q, tile column t, live tile a); q = 4 exists for t = 0 only, q = 5 for t = 1 only
 __host__ __device__ constexpr int w8_block(int q, int t, int a) { return q < 4 ? (q * 2 + t) * NACT + a : 8 * NACT + t * NACT + a; }
@@ -117,7 +130,11 @@ __device__ __forceinline__ void strip8w_body(float* __restrict__ ring, const flo
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j0 = tj8 * 2 * TP, HW = H * W;
-    const int col0 = j0 - DT + role;                                 // role 1 window is shifted by one; NOT clamped to the map
+    // First window column, NOT clamped to the map, the same for both roles: role 0 needs displaced columns j0-8 .. j0+14,
+    // role 1 centre columns j0-7 .. j0+15 -- both inside the 24 columns from j0-8, and with j0 a multiple of 8 no 16-byte
+    // piece straddles column 0 (a piece that starts in front of the buffer is dropped WHOLE by the range check -- its
+    // dwords are checked one by one without wrapping -- so a straddling piece would lose the map's column 0).
+    const int col0 = j0 - DT;
     const float* S = (role ? fm0 : fm1) + (size_t)b * C * HW;
     float* gx = (role ? g1 : g0) + (size_t)b * C * HW;
     const float* gb = gout + (size_t)b * HW * CELLS;
@@ -158,12 +175,12 @@ __device__ __forceinline__ void strip8w_body(float* __restrict__ ring, const flo
             return w8_block(q, t, a) * 64 + l;
         }
     };
-    Quad8w qd[W8_NQ];
-    int er[W8_NQ];
+    Quad8w qd[W8_NQ];                                                // .info also carries the ring quad index (bits 20-31)
 #pragma unroll
     for (int k = 0; k < W8_NQ; ++k) {
-        er[k] = ring_index(tid + k * W8_T);
-        qd[k] = quad8w_desc(role, er[k], H, W, tiles_i, j0, col0);
+        const int e = ring_index(tid + k * W8_T);
+        qd[k] = quad8w_desc(role, e, H, W, tiles_i, j0, col0);
+        qd[k].info |= e << 20;
     }
     const int g_step = 4 * W * CELLS * 4;                            // gradOut bytes per 4 map rows
     auto g_load = [&](int k, int ss) -> f32x4 {
@@ -173,11 +190,11 @@ __device__ __forceinline__ void strip8w_body(float* __restrict__ ring, const flo
     };
     auto g_put = [&](float* rb, int k, const f32x4& raw) {
         const f32x4 v = quad8w_fix(raw, qd[k].info);
-        const int e = er[k];
-        if (!role) { reinterpret_cast<f32x4*>(rb)[e] = v; return; }
-        // role 1: component s = e & 3 of the quads of lanes (tpi * 4 + c, gg), c = 0..3
+        const int e = (unsigned)qd[k].info >> 20, f = w8_swz(e >> 4); // logical quad, the swizzle of its lane group
+        if (!role) { reinterpret_cast<f32x4*>(rb)[e ^ f] = v; return; }
+        // role 1: component s = e & 3 of the quads of lanes (tpi * 4 + c, gg), c = 0..3 (physical slot: ^ f)
         float* w = rb + ((e & ~3) << 2) + (e & 3);
-        w[0] = v[0]; w[4] = v[1]; w[8] = v[2]; w[12] = v[3];
+        w[(0 ^ f) << 2] = v[0]; w[(1 ^ f) << 2] = v[1]; w[(2 ^ f) << 2] = v[2]; w[(3 ^ f) << 2] = v[3];
     };
     f32x4 gn[W8_NQ];
     auto g_load_all = [&](int ss) {
@@ -224,23 +241,26 @@ __device__ __forceinline__ void strip8w_body(float* __restrict__ ring, const flo
     g_load_all(1);
     lds_barrier();
 
-    const f32x4* lane_ring = reinterpret_cast<const f32x4*>(ring) + lane;
-    f32x4 bvP[2][NACT], bvQ[2][NACT];
-    // fragments of k-block q: both tile columns for q < 4, column A for q = 4, column B for q = 5
-    auto b_fetch = [&](f32x4 (&bv)[2][NACT], int buf, int q, auto lo_c, auto hi_c) {
+    const f32x4* ring4 = reinterpret_cast<const f32x4*>(ring);
+    const int lane_sw = lane ^ w8_swz(g);
+    // A super-step is TEN halves of 20 MFMAs: (k-block 0, column A), (0, B), (1, A), ... (3, B), (4, A), (5, B).  A half needs
+    // the five fragments (live tiles) of ONE tile column, so the two register sets that swap roles hold 5 quads each (with whole
+    // k-blocks -- both columns at once -- they held 10 each and the kernel sat at the 256-register limit, spilling around
+    // the steady state).  Ten halves: the sets end a super-step in the roles they started it with.
+    f32x4 bvP[NACT], bvQ[NACT];
+    auto half_q = [](int h) { return h < 8 ? h >> 1 : h - 4; };      // k-block of half h
+    auto half_t = [](int h) { return h < 8 ? h & 1 : h - 8; };       // tile column of half h
+    auto b_fetch = [&](f32x4 (&bv)[NACT], int buf, int h, auto lo_c, auto hi_c) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        const int q = half_q(h), t = half_t(h);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if ((q == 4 && t == 1) || (q == 5 && t == 0)) continue;
-#pragma unroll
-            for (int a = LO; a < HI; ++a) bv[t][a] = lane_ring[buf * (W8_RING / 4) + w8_block(q, t, a) * 64];
-        }
+        for (int a = LO; a < HI; ++a) bv[a] = ring4[buf * (W8_RING / 4) + w8_block(q, t, a) * 64 + lane_sw];
     };
 
     auto super_step = [&](int ss, auto lo_c, auto hi_c, auto nlo_c, auto nhi_c) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         const int cur = ss & 1;
-        auto mfma = [&](const f32x4 (&bv)[2][NACT], int q, int s_lo, int s_hi) {
+        auto mfma = [&](const f32x4 (&bv)[NACT], int q, int t, int s_lo, int s_hi) {
             // the last super-step of a map whose height is not a multiple of 4: slot rows >= H carry G = 0
             if (HI == NACT - 2 && q < 4 && 4 * ss + q >= H) return;  // wave-uniform
             // One k-block of a tile is structurally zero: role 0 the row-3 block of its oldest live tile (that row lies
@@ -250,42 +270,42 @@ __device__ __forceinline__ void strip8w_body(float* __restrict__ ring, const flo
 #pragma unroll
             for (int s = s_lo; s < s_hi; ++s)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if ((q == 4 && t == 1) || (q == 5 && t == 0)) continue;
-#pragma unroll
-                    for (int a = A0; a < A1; ++a) acc[t][a] = D2T_MFMA(a4[q][s], bv[t][a][s], acc[t][a]);
-                }
+                for (int a = A0; a < A1; ++a) acc[t][a] = D2T_MFMA(a4[q][s], bv[a][s], acc[t][a]);
         };
-        auto kblock = [&](f32x4 (&bv)[2][NACT], f32x4 (&bvn)[2][NACT], auto q_c) {
-            constexpr int q = decltype(q_c)::value;
-            mfma(bv, q, 0, 1);
+        auto half = [&](f32x4 (&bv)[NACT], f32x4 (&bvn)[NACT], auto h_c) {
+            constexpr int h = decltype(h_c)::value, q = h < 8 ? h >> 1 : h - 4, t = h < 8 ? h & 1 : h - 8;
+            mfma(bv, q, t, 0, 1);
             D2T_PIN();
-            if (q + 1 < W8_KB) b_fetch(bvn, cur, q + 1, lo_c, hi_c);  // next k-block's G fragments
+            if (h + 1 < 10 && !(W8_ABL & 16)) b_fetch(bvn, cur, h + 1, lo_c, hi_c);    // the next half's G fragments
             D2T_PIN();
-            mfma(bv, q, 1, 2);
+            mfma(bv, q, t, 1, 2);
             D2T_PIN();
-            if (q == 0) store_tile(done, ss - 3);                    // complete since the end of the previous super-step
-            if (q == 1) g_put_all(ring + (cur ^ 1) * W8_RING);       // G(ss+1), requested a super-step ago; that buffer was last read in ss-1
-            if (q == 2) g_load_all(ss + 2);                          // past the map: out of range, zeros
+            if (h == 0 && !(W8_ABL & 4)) store_tile(done, ss - 3);   // complete since the end of the previous super-step
+            if (h == 0 && (W8_ABL & 4)) asm volatile("" ::"v"(done[0]), "v"(done[1]));
+            if (h == 2 && !(W8_ABL & 2)) g_put_all(ring + (cur ^ 1) * W8_RING);       // G(ss+1), requested a super-step ago; that buffer was last read in ss-1
+            if (h == 4 && !(W8_ABL & 1)) g_load_all(ss + 2);         // past the map: out of range, zeros
             D2T_PIN();
-            mfma(bv, q, 2, 4);
+            mfma(bv, q, t, 2, 4);
             D2T_PIN();
-            a4[q] = s_load(ss + 1, q);                               // a whole super-step ahead
-            if (q == W8_KB - 2) {
+            if ((h >= 8 || t == 1) && !(W8_ABL & 8)) a4[q] = s_load(ss + 1, q);         // this k-block's last MFMA is issued: its piece for the next super-step
+            if (h == 8) {
                 // every wave has issued (and, lgkmcnt(0), received) its last fragments of ring[cur] and written its part
-                // of ring[cur^1]: publish.  The k-block behind the barrier runs from registers.
+                // of ring[cur^1]: publish.  The half behind the barrier runs from registers.
                 lds_barrier();
                 b_fetch(bv, cur ^ 1, 0, nlo_c, nhi_c);               // bv is free: its last MFMA has been issued
             }
             D2T_PIN();
         };
-        // six k-blocks: the two register sets end the super-step in the roles they started it with
-        kblock(bvP, bvQ, J0{});
-        kblock(bvQ, bvP, J1{});
-        kblock(bvP, bvQ, J2{});
-        kblock(bvQ, bvP, J3{});
-        kblock(bvP, bvQ, J4{});                                      // ends with the barrier; refills bvP with (ss+1, k-block 0)
-        kblock(bvQ, bvP, J5{});
+        half(bvP, bvQ, J0{});
+        half(bvQ, bvP, J1{});
+        half(bvP, bvQ, J2{});
+        half(bvQ, bvP, J3{});
+        half(bvP, bvQ, J4{});
+        half(bvQ, bvP, J5{});
+        half(bvP, bvQ, std::integral_constant<int, 6>{});
+        half(bvQ, bvP, std::integral_constant<int, 7>{});
+        half(bvP, bvQ, std::integral_constant<int, 8>{});           // ends with the barrier; refills bvP with (ss+1, half 0)
+        half(bvQ, bvP, std::integral_constant<int, 9>{});
         // tile ss-2 is complete: keep it for the store in the next super-step, rotate
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -298,17 +318,40 @@ __device__ __forceinline__ void strip8w_body(float* __restrict__ ring, const flo
     };
 
     b_fetch(bvP, 0, 0, J2{}, J5{});
-    // tiles_i >= 5 (host-checked): two leading, tiles_i - 4 full, two trailing super-steps
+    // tiles_i >= 5 (host-checked): two leading, tiles_i - 4 full, two trailing super-steps.  ONE loop with a wave-uniform
+    // switch over the live ranges instead of peeled straight-line code: with the super-step number a run-time value the
+    // compiler cannot fold it into the addresses of the leading / trailing super-steps (the peeled form did, kept them all
+    // live and spilled 75 registers there: 59 MB written per launch against 39 MB of gradients), and every phase is
+    // register-allocated against the same loop header as the steady state, which does not spill.
+#if W8_LOOP
+    {
+        const int last_full = tiles_i - 3;                           // full super-steps 2 .. tiles_i-3
+#pragma unroll 1
+        for (int ss = 0; ss < tiles_i; ++ss) {
+            const int ph = ss < 2 ? ss : (ss < last_full ? 2 : ss - last_full + 3);
+            switch (ph) {
+                case 0: super_step(ss, J2{}, J5{}, J1{}, J5{}); break;
+                case 1: super_step(ss, J1{}, J5{}, J0{}, J5{}); break;
+                case 2: super_step(ss, J0{}, J5{}, J0{}, J5{}); break;
+                case 3: super_step(ss, J0{}, J5{}, J0{}, J4{}); break;
+                case 4: super_step(ss, J0{}, J4{}, J0{}, J3{}); break;
+                default: super_step(ss, J0{}, J3{}, J0{}, J3{}); break;
+            }
+        }
+    }
+#else
     super_step(0, J2{}, J5{}, J1{}, J5{});
     super_step(1, J1{}, J5{}, J0{}, J5{});
     {
         int ss = 2;
         const int last_full = tiles_i - 3;                           // full super-steps 2 .. tiles_i-3
+#pragma unroll 1
         for (; ss < last_full; ++ss) super_step(ss, J0{}, J5{}, J0{}, J5{});
         super_step(ss, J0{}, J5{}, J0{}, J4{});
         super_step(ss + 1, J0{}, J4{}, J0{}, J3{});
         super_step(ss + 2, J0{}, J3{}, J0{}, J3{});
     }
+#endif
     store_tile(done, tiles_i - 3);
     {
         f32x4 t0[2], t1[2];
@@ -349,6 +392,8 @@ k_corr_bwd_strip8w(const float* __restrict__ gout, const float* __restrict__ fm0
     // rows of S) and both roles of a batch item (they share gradOut[b]).
     const int nb = gridDim.y, lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * nb);
     const int tj8 = lid % tiles_j8, yb = (lid / tiles_j8) % nb, role = (lid / (tiles_j8 * nb)) & 1, b = lid / (2 * tiles_j8 * nb);
+    if ((W8_ABL & 32) && role) return;                               // lab: role 0 alone on the chip
+    if ((W8_ABL & 64) && !role) return;                              // lab: role 1 alone
     if (role) strip8w_body<1>(ring8w, gout, fm0, fm1, g0, g1, b, tj8, yb, C, H, W, tiles_i);
     else strip8w_body<0>(ring8w, gout, fm0, fm1, g0, g1, b, tj8, yb, C, H, W, tiles_i);
 }
