@@ -62,6 +62,8 @@ def parse_args(argv=None):
     p.add_argument("--gpus", type=int, default=1, help="ranks (BASELINE config 5); launch with torch.distributed.run, one rank per GPU")
     p.add_argument("--bucket-mb", type=float, default=64.0, help="gradient all-reduce bucket size")
     p.add_argument("--backend", default="nccl", help="nccl = RCCL (one GPU per rank); gloo lets several ranks rehearse on ONE GPU")
+    p.add_argument("--per-pair", action="store_true", help="the reference's Python loop over the pairs of a minibatch (B = 1 op calls) instead of "
+                   "one batched pass (training.py: forward_loss_pairs)")
     p.add_argument("--exact-tracker", action="store_true", help="keep the tracker's correlation forward bit-identical to the reference (default dispatch) "
                    "instead of D2T_IMPL_FAST")
     p.add_argument("--miopen-find", action="store_true", help="let MIOpen benchmark its convolution algorithms (torch.backends.cudnn.benchmark): "
@@ -73,7 +75,7 @@ class OpTimer:
     """Brackets every tensor-level entry point of the HIP library with events on the current stream."""
     NAMES = ("pointwise_correlation_forward", "pointwise_correlation_backward",
              "pointwise_correlation_levels_forward", "pointwise_correlation_levels_backward",
-             "roipool_forward", "roipool_backward", "ps_roipool_forward", "ps_roipool_backward", "region_filter")
+             "roipool_forward", "roipool_backward", "ps_roipool_forward", "ps_roipool_backward", "region_filter", "region_filter_batched")
 
     def __init__(self, ext):
         self.pending = []
@@ -168,7 +170,7 @@ def main(argv=None):
     # indexed: draw every minibatch of the run BEFORE anything is timed, so that step_ms holds the training step only.
     batches = iter([next(loader) for _ in range(n_steps)])
     torch.cuda.synchronize()
-    trainer = DataParallelTrainer(model, optim, coefs, regions, buckets)
+    trainer = DataParallelTrainer(model, optim, coefs, regions, buckets, batched=not args.per_pair)
     sections = DataParallelTrainer.SECTIONS
 
     def step(record):
@@ -228,12 +230,12 @@ def main(argv=None):
     fam = {"correlation": sum(v for k, v in ops.items() if k.startswith("pointwise")),
            "roipool": sum(v for k, v in ops.items() if k.startswith("roipool")),
            "ps_roipool": sum(v for k, v in ops.items() if k.startswith("ps_roipool")),
-           "region_filter": ops.get("region_filter", 0.0)}
+           "region_filter": ops.get("region_filter", 0.0) + ops.get("region_filter_batched", 0.0)}
     ops_ms = sum(fam.values())
     line = {
         "bench": "DetectTrack training step (BASELINE config %d)" % (4 if world == 1 else 5), "n_gpus": world, "scaling": "weak",
         "parallelism": f"dp{world}" if world > 1 else "single", "dtype": "f32", "data": "synthetic",
-        "weights": "random", "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find),
+        "weights": "random", "pairs_batched": not args.per_pair, "tracker_fast_forward": not args.exact_tracker, "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find),
         "config": {"workload": f"detecttrack_{args.backbone}_B{B}pairs_3x{H}x{W}", "pairs": B, "frame": [3, H, W],
                    "c4": [fh, fw], "regions_per_frame": R, "tracked_boxes": Rt, "anchors": n_anchor},
         "ms_per_step": step_ms, "pairs_per_s": world * B / step_ms * 1e3, "pairs_per_gpu": B, "finite": finite, "max_abs_activation": amax,

@@ -375,22 +375,33 @@ int d2t_region_filter_f32(const float* anchors, const float* offsets, const floa
                           float* out_boxes, float* out_conf, int32_t* out_idx, int32_t* out_count,
                           void* ws, size_t ws_bytes, d2t_stream_t stream)
 {
+    return d2t_region_filter_batched_f32(anchors, offsets, confs, 1, A, conf_thresh, max_dets, iou_thresh,
+                                         out_boxes, out_conf, out_idx, out_count, ws, ws_bytes, stream);
+}
+
+int d2t_region_filter_batched_f32(const float* anchors, const float* offsets, const float* confs, int N, int A,
+                                  float conf_thresh, int max_dets, float iou_thresh,
+                                  float* out_boxes, float* out_conf, int32_t* out_idx, int32_t* out_count,
+                                  void* ws, size_t ws_bytes, d2t_stream_t stream)
+{
+    if (N < 0 || N > 65535) return D2T_EINVAL;
+    if (N == 0) return D2T_OK;
     if (A < 0 || max_dets < 1 || max_dets > region_max_dets() || !out_boxes || !out_conf || !out_idx || !out_count) return D2T_EINVAL;
     if (A > 0 && (!anchors || !offsets || !confs)) return D2T_EINVAL;
     // boxes are moved as float4 / u32x4: a pointer that is only 4-byte aligned would fault on the device
     if (((reinterpret_cast<uintptr_t>(anchors) | reinterpret_cast<uintptr_t>(offsets) | reinterpret_cast<uintptr_t>(out_boxes) |
           reinterpret_cast<uintptr_t>(ws)) & 15) != 0) return D2T_EINVAL;
-    if (!fits_i32(4LL * A)) return D2T_ETOOBIG;
-    if (A == 0) {                                                    // nothing to filter: an all-padding list
-        hipError_t e = hipMemsetAsync(out_boxes, 0, (size_t)max_dets * 16, as_stream(stream));
-        if (e == hipSuccess) e = hipMemsetAsync(out_conf, 0, (size_t)max_dets * 4, as_stream(stream));
-        if (e == hipSuccess) e = hipMemsetAsync(out_idx, 0xff, (size_t)max_dets * 4, as_stream(stream));
-        if (e == hipSuccess) e = hipMemsetAsync(out_count, 0, 4, as_stream(stream));
+    if (!fits_i32(4LL * A) || !fits_i32(4LL * A * N) || !fits_i32(4LL * max_dets * N)) return D2T_ETOOBIG;
+    if (A == 0) {                                                    // nothing to filter: all-padding lists
+        hipError_t e = hipMemsetAsync(out_boxes, 0, (size_t)N * max_dets * 16, as_stream(stream));
+        if (e == hipSuccess) e = hipMemsetAsync(out_conf, 0, (size_t)N * max_dets * 4, as_stream(stream));
+        if (e == hipSuccess) e = hipMemsetAsync(out_idx, 0xff, (size_t)N * max_dets * 4, as_stream(stream));
+        if (e == hipSuccess) e = hipMemsetAsync(out_count, 0, (size_t)N * 4, as_stream(stream));
         return e == hipSuccess ? D2T_OK : static_cast<int>(e);
     }
-    if (!ws || ws_bytes < region_filter_ws_bytes(A, max_dets)) return D2T_EWS;
+    if (!ws || ws_bytes < (size_t)N * region_filter_ws_bytes(A, max_dets)) return D2T_EWS;
     return region_filter_f32(anchors, offsets, confs, A, conf_thresh, max_dets, iou_thresh, out_boxes, out_conf, out_idx, out_count,
-                             ws, as_stream(stream));
+                             ws, as_stream(stream), N);
 }
 
 }  // extern "C"

@@ -141,6 +141,9 @@ typedef std::integral_constant<int, 5> I5;
 #ifndef D2T_EXP_GCO
 #define D2T_EXP_GCO 1
 #endif
+#ifndef S8_ABL
+#define S8_ABL 0      // timing ablations (lab builds only, results are wrong): 1 no S reloads, 2 no tile stores, 4 no G loads, 8 no ring writes, 32 role 0 alone, 64 role 1 alone
+#endif
 template <int role, int S8_CT, bool ROWKB, int ABL = 0, bool FLEX = false>    // ABL: ablation mask of csrc/lab/bwd8_stamp_lab (timing only)
 __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const float* __restrict__ gout,
                                             const float* __restrict__ fm0, const float* __restrict__ fm1,
@@ -453,6 +456,8 @@ k_corr_bwd_strip8(const float* __restrict__ gout, const float* __restrict__ fm0,
     const int Ct = (C + 15) / 16;                                    // FLEX: gridDim.y blocks of consecutive c-tiles, sizes differ by at most one
     const int ct0 = FLEX ? (int)((long long)yb * Ct / nb) : 16 * yb;
     const int nct = FLEX ? (int)((long long)(yb + 1) * Ct / nb) - ct0 : 16;
+    if ((S8_ABL & 32) && role) return;
+    if ((S8_ABL & 64) && !role) return;
     if (role) strip8_body<1, CT, ROWKB, ABL, FLEX>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i, ct0, nct);
     else strip8_body<0, CT, ROWKB, ABL, FLEX>(ring, gout, fm0, fm1, g0, g1, b, tj, C, H, W, tiles_i, ct0, nct);
 }
@@ -506,7 +511,7 @@ int corr_bwd8_f32(const float* gout, const float* fm0, const float* fm1, float* 
         hipLaunchKernelGGL((k_corr_bwd_strip8<2, false>), dim3(2 * B * tiles_j, (C + S8_CH - 1) / S8_CH), dim3(512), 0, st,
                            gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
     } else if (C % S8_CH == 0 && nb == C / S8_CH) {                   // whole 256-channel blocks (the metric shape): no branches
-        hipLaunchKernelGGL((k_corr_bwd_strip8<2, true>), dim3(2 * B * tiles_j, nb), dim3(512), 0, st,
+        hipLaunchKernelGGL((k_corr_bwd_strip8<2, true, (S8_ABL & 15)>), dim3(2 * B * tiles_j, nb), dim3(512), 0, st,
                            gout, fm0, fm1, g0, g1, B, C, H, W, tiles_i, tiles_j);
     } else {
         hipLaunchKernelGGL((k_corr_bwd_strip8<2, true, 0, true>), dim3(2 * B * tiles_j, nb), dim3(512), 0, st,

@@ -34,6 +34,6 @@ size_t region_filter_ws_bytes(int A, int max_dets);
 int region_max_dets();
 int region_filter_f32(const float* anchors, const float* offsets, const float* confs, int A,
                       float conf_thresh, int max_dets, float iou_thresh,
-                      float* out_boxes, float* out_conf, int* out_idx, int* out_count, void* ws, hipStream_t st);
+                      float* out_boxes, float* out_conf, int* out_idx, int* out_count, void* ws, hipStream_t st, int N = 1);
 
 }  // namespace d2t

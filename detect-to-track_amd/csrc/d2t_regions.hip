@@ -15,6 +15,7 @@
 // Boxes are (centre_i, centre_j, height, width) fractions of the frame, as everywhere in the reference.
 #include "d2t_kernels.hpp"
 
+#include <type_traits>
 namespace d2t {
 
 namespace {
@@ -32,11 +33,20 @@ __device__ __forceinline__ unsigned order_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Batched calls (several frames of one step, SURVEY 8f-1 / trainer.py:178-207 per frame): blockIdx.z = frame.  The anchors
+// are shared; offsets / confidences / outputs of frame f follow those of frame f-1; every frame has its own copy of the
+// workspace layout, ws_stride bytes apart.
+template <typename T>
+__device__ __forceinline__ T* frame_ws(T* p, size_t ws_stride, int f) { return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + (size_t)f * ws_stride); }
+
 // data/encoding.py:182-206: b_ij = t_ij * a_hw + a_ij,  b_hw = exp(t_hw) * a_hw   (unfused, as numpy evaluates them)
 __global__ void __launch_bounds__(256)
 k_region_decode(const float* __restrict__ anchors, const float* __restrict__ offsets, const float* __restrict__ confs,
-                float* __restrict__ boxes, unsigned* __restrict__ keys, int A, float thresh)
+                float* __restrict__ boxes, unsigned* __restrict__ keys, int A, float thresh, size_t ws_stride)
 {
+    const int f = blockIdx.z;
+    offsets += (size_t)f * A * 4; confs += (size_t)f * A;
+    boxes = frame_ws(boxes, ws_stride, f); keys = frame_ws(keys, ws_stride, f);
     const int a = blockIdx.x * 256 + threadIdx.x;
     if (a >= A) {
         if (a < ((A + 3) & ~3)) keys[a] = 0u;                        // the selection reads keys 16 bytes at a time
@@ -132,7 +142,7 @@ __global__ void __launch_bounds__(RG_T)
 k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes, const float* __restrict__ confs,
               float* __restrict__ sboxes, float* __restrict__ sconf, int* __restrict__ sidx, int* __restrict__ nsel,
               float* __restrict__ out_boxes, float* __restrict__ out_conf, int* __restrict__ out_idx, int* __restrict__ out_count,
-              int A, int K, int NS, float iou)
+              int A, int K, int NS, float iou, size_t ws_stride)
 {   // NS: the sorting network's size, the power of two >= K (<= RG_MAXK); keys is padded with zeros to a multiple of 4
     __shared__ unsigned hist[RG_BINS];
     __shared__ unsigned long long cand[RG_MAXK];                     // candidates; later the fused path's bit matrix
@@ -141,6 +151,13 @@ k_region_topk(const unsigned* __restrict__ keys, const float* __restrict__ boxes
     __shared__ float4 sb[FUSED ? RG_FUSE : 1];
     __shared__ float sc[FUSED ? RG_FUSE : 1];
     __shared__ int si[FUSED ? RG_FUSE : 1];
+    {
+        const int f = blockIdx.z;                                    // frame of a batched call
+        keys = frame_ws(keys, ws_stride, f); boxes = frame_ws(boxes, ws_stride, f); confs += (size_t)f * A;
+        sboxes = frame_ws(sboxes, ws_stride, f); sconf = frame_ws(sconf, ws_stride, f); sidx = frame_ws(sidx, ws_stride, f);
+        nsel = frame_ws(nsel, ws_stride, f);
+        out_boxes += (size_t)f * K * 4; out_conf += (size_t)f * K; out_idx += (size_t)f * K; out_count += f;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int A4 = (A + 3) >> 2;                                     // 16-byte pieces of the key array
 
@@ -350,8 +367,10 @@ __device__ __forceinline__ bool iou_exceeds(const float4& a, const float4& b, fl
 
 // mask[i][w] bit j: box 64w+j comes later than box i and overlaps it by more than `iou`
 __global__ void __launch_bounds__(64)
-k_region_mask(const float* __restrict__ sboxes, const int* __restrict__ nsel, unsigned long long* __restrict__ mask, float iou)
+k_region_mask(const float* __restrict__ sboxes, const int* __restrict__ nsel, unsigned long long* __restrict__ mask, float iou,
+              size_t ws_stride)
 {
+    sboxes = frame_ws(sboxes, ws_stride, blockIdx.z); nsel = frame_ws(nsel, ws_stride, blockIdx.z); mask = frame_ws(mask, ws_stride, blockIdx.z);
     const int n = *nsel, rb = blockIdx.y, cb = blockIdx.x, lane = threadIdx.x;
     if (64 * rb >= n || 64 * cb >= n || cb < rb) return;             // (rows beyond n are never read; words left of the diagonal are zeroed below)
     __shared__ float4 col[64];
@@ -377,8 +396,15 @@ k_region_mask(const float* __restrict__ sboxes, const int* __restrict__ nsel, un
 __global__ void __launch_bounds__(RG_T)
 k_region_nms(const float* __restrict__ sboxes, const float* __restrict__ sconf, const int* __restrict__ sidx,
              const int* __restrict__ nsel, const unsigned long long* __restrict__ mask,
-             float* __restrict__ out_boxes, float* __restrict__ out_conf, int* __restrict__ out_idx, int* __restrict__ out_count, int K)
+             float* __restrict__ out_boxes, float* __restrict__ out_conf, int* __restrict__ out_idx, int* __restrict__ out_count, int K,
+             size_t ws_stride)
 {
+    {
+        const int f = blockIdx.z;
+        sboxes = frame_ws(sboxes, ws_stride, f); sconf = frame_ws(sconf, ws_stride, f); sidx = frame_ws(sidx, ws_stride, f);
+        nsel = frame_ws(nsel, ws_stride, f); mask = frame_ws(mask, ws_stride, f);
+        out_boxes += (size_t)f * K * 4; out_conf += (size_t)f * K; out_idx += (size_t)f * K; out_count += f;
+    }
     __shared__ unsigned long long rows[64][RG_W + 1];
     __shared__ unsigned long long keepw[RG_W];                       // per block: its survivors ...
     __shared__ int keptb[RG_W + 1];                                  // ... and how many came before them
@@ -467,8 +493,9 @@ size_t region_filter_ws_bytes(int A, int max_dets)
 
 int region_filter_f32(const float* anchors, const float* offsets, const float* confs, int A,
                       float conf_thresh, int max_dets, float iou_thresh,
-                      float* out_boxes, float* out_conf, int* out_idx, int* out_count, void* ws, hipStream_t st)
+                      float* out_boxes, float* out_conf, int* out_idx, int* out_count, void* ws, hipStream_t st, int N)
 {
+    const size_t ws_stride = region_filter_ws_bytes(A, max_dets);    // frame f works in ws + f * ws_stride
     char* w = static_cast<char*>(ws);
     float* boxes = reinterpret_cast<float*>(w); w += al256((size_t)A * 16);
     unsigned* keys = reinterpret_cast<unsigned*>(w); w += al256((size_t)A * 4);
@@ -477,12 +504,12 @@ int region_filter_f32(const float* anchors, const float* offsets, const float* c
     int* sidx = reinterpret_cast<int*>(w); w += al256((size_t)RG_MAXK * 4);
     int* nsel = reinterpret_cast<int*>(w); w += 256;
     unsigned long long* mask = reinterpret_cast<unsigned long long*>(w);
-    hipLaunchKernelGGL(k_region_decode, dim3((A + 255) / 256), dim3(256), 0, st, anchors, offsets, confs, boxes, keys, A, conf_thresh);
+    hipLaunchKernelGGL(k_region_decode, dim3((A + 255) / 256, 1, N), dim3(256), 0, st, anchors, offsets, confs, boxes, keys, A, conf_thresh, ws_stride);
     int ns = 64;
     while (ns < max_dets) ns <<= 1;
     const int A4 = (A + 3) / 4;
-#define D2T_TOPK(NV, FUSED) hipLaunchKernelGGL((k_region_topk<NV, FUSED>), dim3(1), dim3(RG_T), 0, st, keys, boxes, confs, sboxes, sconf, sidx, \
-                                               nsel, out_boxes, out_conf, out_idx, out_count, A, max_dets, ns, iou_thresh)
+#define D2T_TOPK(NV, FUSED) hipLaunchKernelGGL((k_region_topk<NV, FUSED>), dim3(1, 1, N), dim3(RG_T), 0, st, keys, boxes, confs, sboxes, sconf, sidx, \
+                                               nsel, out_boxes, out_conf, out_idx, out_count, A, max_dets, ns, iou_thresh, ws_stride)
     const bool fused = max_dets <= RG_FUSE;
     if (fused) {
         if (A4 <= 3 * RG_T) D2T_TOPK(3, true);
@@ -497,8 +524,8 @@ int region_filter_f32(const float* anchors, const float* offsets, const float* c
     else D2T_TOPK(0, false);
 #undef D2T_TOPK
     const int nb = (max_dets + 63) / 64;
-    hipLaunchKernelGGL(k_region_mask, dim3(nb, nb), dim3(64), 0, st, sboxes, nsel, mask, iou_thresh);
-    hipLaunchKernelGGL(k_region_nms, dim3(1), dim3(RG_T), 0, st, sboxes, sconf, sidx, nsel, mask, out_boxes, out_conf, out_idx, out_count, max_dets);
+    hipLaunchKernelGGL(k_region_mask, dim3(nb, nb, N), dim3(64), 0, st, sboxes, nsel, mask, iou_thresh, ws_stride);
+    hipLaunchKernelGGL(k_region_nms, dim3(1, 1, N), dim3(RG_T), 0, st, sboxes, sconf, sidx, nsel, mask, out_boxes, out_conf, out_idx, out_count, max_dets, ws_stride);
     return launch_status();
 }
 

@@ -328,3 +328,32 @@ def region_filter(anchors: Tensor, offsets: Tensor, confs: Tensor, conf_thresh: 
                                                count.data_ptr(), _ptr(ws), n, _stream(anchors))
     _native.check(rc, "region_filter")
     return boxes, conf, idx, count
+
+
+def region_filter_batched(anchors: Tensor, offsets: Tensor, confs: Tensor, conf_thresh: float, max_dets: int, iou_thresh: float):
+    """``region_filter`` for the N frames of a step in ONE call of the library (the reference runs its host pipeline once per
+    frame, trainer.py:178-207): anchors (A,4) shared, offsets (N,A,4), confs (N,A) -> (boxes (N,max_dets,4), confs (N,max_dets),
+    anchor_index (N,max_dets) int32, count (N,) int32); frame f's slices equal a single-frame call's results bit for bit."""
+    for t, name in ((anchors, "anchors"), (offsets, "offsets"), (confs, "confs")):
+        _check_input(t, name)
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{name} must be float32")
+        _same(t, anchors, name, "anchors")
+    if confs.dim() != 2:
+        raise RuntimeError(f"confs must be (N, A), got {tuple(confs.shape)}")
+    N, A = int(confs.shape[0]), int(confs.shape[1])
+    if tuple(anchors.shape) != (A, 4) or tuple(offsets.shape) != (N, A, 4):
+        raise RuntimeError(f"anchors / offsets must be ({A}, 4) / ({N}, {A}, 4), got {tuple(anchors.shape)} / {tuple(offsets.shape)}")
+    max_dets = int(max_dets)
+    dev = anchors.device
+    with torch.cuda.device(dev):
+        boxes = torch.empty((N, max_dets, 4), dtype=torch.float32, device=dev)
+        conf = torch.empty((N, max_dets), dtype=torch.float32, device=dev)
+        idx = torch.empty((N, max_dets), dtype=torch.int32, device=dev)
+        count = torch.empty((N,), dtype=torch.int32, device=dev)
+        ws, n = _workspace(N * _native.lib.d2t_region_filter_workspace_bytes(A, max_dets), anchors)
+        rc = _native.lib.d2t_region_filter_batched_f32(anchors.data_ptr(), offsets.data_ptr(), confs.data_ptr(), N, A, float(conf_thresh),
+                                                       max_dets, float(iou_thresh), boxes.data_ptr(), conf.data_ptr(), idx.data_ptr(),
+                                                       count.data_ptr(), _ptr(ws), n, _stream(anchors))
+    _native.check(rc, "region_filter_batched")
+    return boxes, conf, idx, count

@@ -84,7 +84,9 @@ LAYOUT_REFERENCE, LAYOUT_CHANNEL_MAJOR = 0, 1
 # (A, max_dets) ; (anchors, offsets, confs, A, conf_thresh, max_dets, iou_thresh, out_boxes, out_conf, out_idx, out_count, ws, ws_bytes, stream)
 _proto("d2t_region_filter_workspace_bytes", _Z, [_I, _I])
 _proto("d2t_region_filter_f32", _I, [_P, _P, _P, _I, ctypes.c_float, _I, ctypes.c_float, _P, _P, _P, _P, _P, _Z, _P])
-SYMBOLS += ["d2t_region_filter_workspace_bytes", "d2t_region_filter_f32"]
+# (anchors, offsets, confs, N, A, conf_thresh, max_dets, iou_thresh, out_boxes, out_conf, out_idx, out_count, ws, ws_bytes, stream)
+_proto("d2t_region_filter_batched_f32", _I, [_P, _P, _P, _I, _I, ctypes.c_float, _I, ctypes.c_float, _P, _P, _P, _P, _P, _Z, _P])
+SYMBOLS += ["d2t_region_filter_workspace_bytes", "d2t_region_filter_f32", "d2t_region_filter_batched_f32"]
 _proto("d2t_psroipool_channels", _I, [_P, _I, _I, _P])
 _proto("d2t_corr_mask", _I, [_P, _I, _I, _I, _I, _P])
 SYMBOLS += ["d2t_psroipool_channels", "d2t_corr_mask"]

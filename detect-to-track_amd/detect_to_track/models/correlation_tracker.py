@@ -26,32 +26,38 @@ from .roipool.roipool import ROIPool
 
 class TrackFeaturesFunction(Function):
     """(reg_fm_0, reg_fm_1, [FM0_l, FM1_l] x L) -> (2*Cr + L*(2d+1)^2, H, W), the tensor the reference
-    builds at correlation_tracker.py:64-80.  FM*_l: (1, C_l, H, W) float32."""
+    builds at correlation_tracker.py:64-80.  FM*_l: (1, C_l, H, W) float32.
+    Batched over the P pairs of a step: reg_fm_* (P, Cr, H, W), FM*_l (P, C_l, H, W) -> (P, 2*Cr + L*(2d+1)^2, H, W) with
+    ONE call of the library for all pairs and levels (the reference loops over pairs, trainer.py:263-264)."""
 
     @staticmethod
     def forward(ctx, d_max: int, stride: int, impl: int, reg_fm_0: Tensor, reg_fm_1: Tensor, *fms: Tensor) -> Tensor:
         if len(fms) % 2 or not fms:
             raise RuntimeError("feature maps come in (FM0, FM1) pairs")
         fm0s, fm1s = [f.contiguous() for f in fms[0::2]], [f.contiguous() for f in fms[1::2]]
-        cr = reg_fm_0.size(0)
+        batched = reg_fm_0.dim() == 4
+        if not batched:
+            reg_fm_0, reg_fm_1 = reg_fm_0[None], reg_fm_1[None]
+        cr = reg_fm_0.size(1)
         cells = (2 * d_max + 1) ** 2
-        _, _, H, W = fm0s[0].shape
-        buf = torch.empty((1, 2 * cr + len(fm0s) * cells, H, W), dtype=reg_fm_0.dtype, device=reg_fm_0.device)
-        buf[0, :cr] = reg_fm_0
-        buf[0, cr:2 * cr] = reg_fm_1
+        P, _, H, W = fm0s[0].shape
+        buf = torch.empty((P, 2 * cr + len(fm0s) * cells, H, W), dtype=reg_fm_0.dtype, device=reg_fm_0.device)
+        buf[:, :cr] = reg_fm_0
+        buf[:, cr:2 * cr] = reg_fm_1
         _ext.pointwise_correlation_levels_forward(fm0s, fm1s, d_max, stride, out=(buf, 2 * cr), impl=impl)
         ctx.save_for_backward(*fm0s, *fm1s)
-        ctx.meta = (d_max, stride, cr, len(fm0s))
-        return buf[0]
+        ctx.meta = (d_max, stride, cr, len(fm0s), batched)
+        return buf if batched else buf[0]
 
     @staticmethod
     def backward(ctx, grad: Tensor) -> Tuple[Optional[Tensor], ...]:
-        d_max, stride, cr, L = ctx.meta
+        d_max, stride, cr, L, batched = ctx.meta
         fm0s, fm1s = list(ctx.saved_tensors[:L]), list(ctx.saved_tensors[L:])
         grad = grad.contiguous()
-        g0, g1 = _ext.pointwise_correlation_levels_backward(grad[None], 2 * cr, fm0s, fm1s, d_max, stride)
+        gb = grad if batched else grad[None]
+        g0, g1 = _ext.pointwise_correlation_levels_backward(gb, 2 * cr, fm0s, fm1s, d_max, stride)
         grads = [g for pair in zip(g0, g1) for g in pair]
-        return (None, None, None, grad[:cr], grad[cr:2 * cr], *grads)
+        return (None, None, None, gb[:, :cr] if batched else grad[:cr], gb[:, cr:2 * cr] if batched else grad[cr:2 * cr], *grads)
 
 
 class CorrelationTracker(nn.Module):
@@ -84,6 +90,23 @@ class CorrelationTracker(nn.Module):
         impl = _native.IMPL_FAST if self.fast_forward else _native.IMPL_AUTO
         return TrackFeaturesFunction.apply(self.d_max, self.stride, impl, reg_fm_0, reg_fm_1,
                                            c3_0, c3_1, c4_0, c4_1, c5_0, c5_1)
+
+    def forward_pairs(self, fm_pyrs_0: Mapping[str, Tensor], fm_pyrs_1: Mapping[str, Tensor],
+                      reg_fm_0: Tensor, reg_fm_1: Tensor, rois: "list[Tensor]") -> "list[Tensor]":
+        """The P pairs of a step at once (not in the reference, whose trainer loops over pairs: trainer.py:263-264).
+        fm_pyrs_*: {"c3","c4","c5"} of (P, C, H, W) maps at t / t+tau; reg_fm_*: (P, Cr, H, W); rois: P tensors (|R_p|, 4).
+        ONE fused correlation call for all pairs and levels (B = P fills the chip where B = 1 leaves most of it idle), then
+        ROIPool and the FC per pair on slices of the one buffer.  Pair p's result equals forward() on pair p."""
+        c3_0 = nn.functional.interpolate(fm_pyrs_0["c3"], scale_factor=1 / 2)
+        c3_1 = nn.functional.interpolate(fm_pyrs_1["c3"], scale_factor=1 / 2)
+        impl = _native.IMPL_FAST if self.fast_forward else _native.IMPL_AUTO
+        feats = TrackFeaturesFunction.apply(self.d_max, self.stride, impl, reg_fm_0.contiguous(), reg_fm_1.contiguous(),
+                                            c3_0, c3_1, fm_pyrs_0["c4"], fm_pyrs_1["c4"], fm_pyrs_0["c5"], fm_pyrs_1["c5"])
+        out = []
+        for p, r in enumerate(rois):
+            pooled = self.pool(feats[p], r)
+            out.append(self.reg_fc(pooled.view(pooled.size(0), self.fc_channels)))
+        return out
 
     def forward(self, fm_pyr_0: Mapping[str, Tensor], fm_pyr_1: Mapping[str, Tensor],
                 reg_fm_0: Tensor, reg_fm_1: Tensor, rois: Tensor) -> Tensor:

@@ -122,6 +122,14 @@ class RegionProposals:
                                                 self.conf_thresh, self.max_dets, self.iou_thresh)
         return boxes, count
 
+    @torch.no_grad()
+    def frames(self, obj_conf: Tensor, offsets: Tensor) -> Tuple[Tensor, Tensor]:
+        """All N frames of a step in ONE library call: obj_conf (N, |A|), offsets (N, |A|, 4) -> (boxes (N, max_dets, 4), counts (N,))."""
+        from .models import _ext
+        boxes, _, _, count = _ext.region_filter_batched(self.anchors, offsets.detach().contiguous(), obj_conf.detach().contiguous(),
+                                                        self.conf_thresh, self.max_dets, self.iou_thresh)
+        return boxes, count
+
 
 class DataParallelTrainer:
     """One rank of the training job.  ``buckets`` is a ``data_parallel.GradientBuckets`` over the trainable parameters
@@ -129,8 +137,12 @@ class DataParallelTrainer:
 
     SECTIONS = ("backbone", "rpn", "regions", "rcnn", "tracker", "loss")
 
-    def __init__(self, model, optimizer, loss_coefs: Tensor, regions: RegionProposals, buckets=None) -> None:
-        self.model, self.optim, self.coefs, self.regions, self.buckets = model, optimizer, loss_coefs, regions, buckets
+    def __init__(self, model, optimizer, loss_coefs: Tensor, regions: RegionProposals, buckets=None, batched: bool = False) -> None:
+        """batched: run the P pairs of a minibatch through the model TOGETHER (forward_loss_pairs) instead of the reference's
+        Python loop over pairs (forward_loss): one backbone / RPN pass over the 2P frames, ONE region-filter call for all
+        frames, ONE fused correlation call with B = P for the tracker -- the B = 1 calls of the loop leave most of the chip
+        idle.  Same losses per pair; the convolutions see another batch size, so values agree to rounding, not bit for bit."""
+        self.model, self.optim, self.coefs, self.regions, self.buckets, self.batched = model, optimizer, loss_coefs, regions, buckets, bool(batched)
 
     def forward_loss(self, inst: PairInstance, mark: Optional[Callable[[], object]] = None) -> Tuple[Tensor, list]:
         """The five loss terms of one pair (reference trainer.py:133-256) and, with ``mark``, the section boundaries."""
@@ -163,15 +175,55 @@ class DataParallelTrainer:
         stamps += [mark()] if mark else []
         return losses, stamps
 
+    def forward_loss_pairs(self, minibatch: Sequence[PairInstance], mark: Optional[Callable[[], object]] = None) -> Tuple[Tensor, list]:
+        """forward_loss for the P pairs of a minibatch at once (frames interleaved: pair p = frames 2p, 2p+1).  Returns the
+        SUM over pairs of the five loss terms and one list of section stamps."""
+        m, P = self.model, len(minibatch)
+        stamps = [mark()] if mark else []
+        fmaps = m.backbone(torch.cat([inst.frames for inst in minibatch]))        # (2P, 3, H, W)
+        stamps += [mark()] if mark else []
+        o_hat, b_hat, fm_reg = m.rpn(fmaps["c4"])                                 # (2P, |A|, 2), (2P, |A|, 4), (2P, Cr, h, w)
+        stamps += [mark()] if mark else []
+        rboxes, _ = self.regions.frames(o_hat[:, :, 1], b_hat)                    # one call for the 2P frames
+        stamps += [mark()] if mark else []
+        cls, reg = [], []
+        for f in range(2 * P):                                                    # R-FCN pools one map at a time (rfcn.py:66-84)
+            c, b = m.rcnn(fmaps["c5"][f], rboxes[f])
+            cls.append(c)
+            reg.append(b)
+        stamps += [mark()] if mark else []
+        pyr0 = OrderedDict((k, fmaps[k][0::2]) for k in ("c3", "c4", "c5"))
+        pyr1 = OrderedDict((k, fmaps[k][1::2]) for k in ("c3", "c4", "c5"))
+        t_hats = m.c_tracker.forward_pairs(pyr0, pyr1, fm_reg[0::2], fm_reg[1::2], [inst.track_rois for inst in minibatch])
+        stamps += [mark()] if mark else []
+        nll, sl1 = torch.nn.functional.nll_loss, torch.nn.functional.smooth_l1_loss
+        total = torch.zeros(5, device=self.coefs.device)
+        for p, inst in enumerate(minibatch):
+            o_p, b_p = o_hat[2 * p: 2 * p + 2], b_hat[2 * p: 2 * p + 2]
+            c_hat, r_hat = torch.cat(cls[2 * p: 2 * p + 2]), torch.cat(reg[2 * p: 2 * p + 2])
+            total = total + torch.stack([
+                nll(torch.log(o_p.reshape(-1, 2) + 1e-8), inst.o_star.reshape(-1)),
+                sl1(b_p, inst.b_star),
+                nll(torch.log(c_hat + 1e-8), inst.c_star),
+                sl1(r_hat, inst.r_star),
+                sl1(t_hats[p], inst.t_star),
+            ])
+        stamps += [mark()] if mark else []
+        return total, stamps
+
     def train_step(self, minibatch: Sequence[PairInstance], mark: Optional[Callable[[], object]] = None):
         """trainer.py:258-281 for one minibatch.  Returns (summed losses, per-pair section stamps, (b0, b1, b2) marks
         around backward + all-reduce and the optimizer step)."""
         total = torch.zeros(5, device=self.coefs.device)
         stamps = []
-        for inst in minibatch:                                                    # the reference's Python loop over pairs (:263-264)
-            losses, st = self.forward_loss(inst, mark)
-            total = total + losses
+        if self.batched:
+            total, st = self.forward_loss_pairs(minibatch, mark)
             stamps.append(st)
+        else:
+            for inst in minibatch:                                                # the reference's Python loop over pairs (:263-264)
+                losses, st = self.forward_loss(inst, mark)
+                total = total + losses
+                stamps.append(st)
         if self.buckets is not None:
             self.buckets.zero_grad()                                              # gradients live in (and stay attached to) the buckets
         else:

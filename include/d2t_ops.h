@@ -210,6 +210,14 @@ int d2t_region_filter_f32(const float* anchors, const float* offsets, const floa
                           float conf_thresh, int max_dets, float iou_thresh,
                           float* out_boxes, float* out_conf, int32_t* out_idx, int32_t* out_count,
                           void* ws, size_t ws_bytes, d2t_stream_t stream);
+/* The same for the N frames of a step in ONE call (the reference runs the host pipeline once per frame, trainer.py:178-207):
+ * anchors (A,4) shared; offsets (N,A,4), confs (N,A); out_boxes (N,max_dets,4), out_conf / out_idx (N,max_dets), out_count (N);
+ * ws of N * d2t_region_filter_workspace_bytes(A, max_dets) bytes.  Frame f's results are those of a single-frame call on
+ * frame f's slices, bit for bit.  (max_dets * 16 is a multiple of 16, so every frame's box list stays 16-byte aligned.) */
+int d2t_region_filter_batched_f32(const float* anchors, const float* offsets, const float* confs, int N, int A,
+                                  float conf_thresh, int max_dets, float iou_thresh,
+                                  float* out_boxes, float* out_conf, int32_t* out_idx, int32_t* out_count,
+                                  void* ws, size_t ws_bytes, d2t_stream_t stream);
 
 #ifdef __cplusplus
 }

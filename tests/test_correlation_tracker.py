@@ -169,6 +169,39 @@ def test_module_matches_reference_composition():
         torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-5 * float(y.abs().max()))
 
 
+def test_forward_pairs_equals_per_pair_forward():
+    """CorrelationTracker.forward_pairs (the P pairs of a step through ONE fused correlation call with B = P, SURVEY 8f-1's
+    'batched B > 1 call across pairs') against forward() pair by pair: forward values bit for bit (the same kernels run per
+    batch item), gradients to 1e-5 of their scale (the batched backward may take another kernel for the larger grid)."""
+    from detect_to_track.models import CorrelationTracker
+    torch.manual_seed(7)
+    P, H, W, cr = 3, 38, 63, 16
+    mod = CorrelationTracker(8, 7, cr).to(DEV)
+
+    def leaf(*shape):
+        return torch.rand(*shape, device=DEV).requires_grad_(True)
+    Cs = {"c3": 12, "c4": 20, "c5": 28}
+    p0 = {k: leaf(P, c, (2 * H if k == "c3" else H), (2 * W if k == "c3" else W)) for k, c in Cs.items()}
+    p1 = {k: leaf(P, c, (2 * H if k == "c3" else H), (2 * W if k == "c3" else W)) for k, c in Cs.items()}
+    r0, r1 = leaf(P, cr, H, W), leaf(P, cr, H, W)
+    rois = [torch.tensor([[0.5, 0.5, 0.4, 0.3], [0.2, 0.7, 0.3, 0.5]], device=DEV)[: 1 + p % 2] for p in range(P)]
+    outs = mod.forward_pairs(p0, p1, r0, r1, rois)
+    ws = [torch.rand_like(o) for o in outs]
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    leaves = list(p0.values()) + list(p1.values()) + [r0, r1]
+    g_batched = [x.grad.clone() for x in leaves] + [mod.reg_fc.weight.grad.clone()]
+    for x in leaves:
+        x.grad = None
+    mod.zero_grad()
+    singles = [mod({k: v[p] for k, v in p0.items()}, {k: v[p] for k, v in p1.items()}, r0[p], r1[p], rois[p]) for p in range(P)]
+    for a, b in zip(outs, singles):
+        assert a.shape == b.shape and torch.equal(a, b)
+    sum((o * w).sum() for o, w in zip(singles, ws)).backward()
+    g_single = [x.grad for x in leaves] + [mod.reg_fc.weight.grad]
+    for x, y in zip(g_batched, g_single):
+        torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-5 * float(y.abs().max()))
+
+
 def test_levels_argument_errors():
     from detect_to_track.models import _ext
     a = torch.rand(1, 4, 9, 21, device=DEV)

@@ -74,12 +74,15 @@ def test_training_step_reaches_every_trainable_parameter():
 
 
 @pytest.mark.gpu
-def test_config4_step_at_size_ops_match_reference_kernels(ref_modules, oracle):
+@pytest.mark.parametrize("batched", [False, True], ids=["per_pair", "pairs_batched"])
+def test_config4_step_at_size_ops_match_reference_kernels(batched, ref_modules, oracle):
     """BASELINE config 4 AT SIZE: one training step of B = 2 frame pairs of 3x608x1008 with 300 regions per frame
     (reference shapes: models/detect_track.py:41-55, cfg/default.yaml:45-50), through detect_to_track/training.py --
     region proposals decoded / filtered / NMS-ed on the device from the live RPN outputs.  Every call the step makes
     into libd2t_ops.so is captured at the `_ext` boundary; shapes are asserted, and each FORWARD call is re-run
-    through the reference's own kernels (oracle/_ref) on the captured inputs."""
+    through the reference's own kernels (oracle/_ref) on the captured inputs.  per_pair: the reference's Python loop over
+    pairs (B = 1 op calls); pairs_batched: training.py's forward_loss_pairs -- one region-filter call for the 2B frames, one
+    fused correlation call with B pairs."""
     from detect_to_track.models import DetectTrackModule, _ext
     from detect_to_track.training import BatchLoader, DataParallelTrainer, RegionProposals, SyntheticPairManager, build_anchors
     ref_corr, ref_roi, ref_ps = ref_modules
@@ -93,12 +96,12 @@ def test_config4_step_at_size_ops_match_reference_kernels(ref_modules, oracle):
     assert anchors.shape == (fh * fw * 15, 4)
     params = [p for p in model.parameters() if p.requires_grad]
     trainer = DataParallelTrainer(model, torch.optim.SGD(params, lr=1e-6), torch.tensor([1., 1., 1., 1., 1e-4], device=dev),
-                                  RegionProposals(anchors, 0.3, R, 0.5, dev))
+                                  RegionProposals(anchors, 0.3, R, 0.5, dev), batched=batched)
     manager = SyntheticPairManager(B, (H, W), len(anchors), R, T, 30, dev, seed=5)
 
     calls = []
     names = ("pointwise_correlation_levels_forward", "pointwise_correlation_levels_backward", "roipool_forward", "roipool_backward",
-             "ps_roipool_forward", "ps_roipool_backward", "region_filter")
+             "ps_roipool_forward", "ps_roipool_backward", "region_filter", "region_filter_batched")
     saved = {n: getattr(_ext, n) for n in names}
 
     def wrap(name):
@@ -120,8 +123,11 @@ def test_config4_step_at_size_ops_match_reference_kernels(ref_modules, oracle):
         assert (p.grad is not None) == p.requires_grad and (p.grad is None or torch.isfinite(p.grad).all()), name
     count = {n: sum(1 for c in calls if c[0] == n) for n in names}
     # per pair: 2 region filters, 2 frames x 2 heads PSROIPool, 1 fused 3-level correlation + 1 ROIPool; backward of each
-    assert count == {"pointwise_correlation_levels_forward": B, "pointwise_correlation_levels_backward": B, "roipool_forward": B,
-                     "roipool_backward": B, "ps_roipool_forward": 4 * B, "ps_roipool_backward": 4 * B, "region_filter": 2 * B}, count
+    nc = 1 if batched else B                                       # fused correlation calls: one for all pairs, or one per pair
+    assert count == {"pointwise_correlation_levels_forward": nc, "pointwise_correlation_levels_backward": nc, "roipool_forward": B,
+                     "roipool_backward": B, "ps_roipool_forward": 4 * B, "ps_roipool_backward": 4 * B,
+                     "region_filter": 0 if batched else 2 * B, "region_filter_batched": 1 if batched else 0}, count
+    PB = B if batched else 1                                       # batch size of a fused correlation call
     cells = 289
     for name, a, _, out in calls:
         if name == "region_filter":
@@ -129,6 +135,14 @@ def test_config4_step_at_size_ops_match_reference_kernels(ref_modules, oracle):
             assert tuple(anc.shape) == (fh * fw * 15, 4) and tuple(out[0].shape) == (R, 4)
             n = int(out[3])
             assert 0 < n <= R and not out[0][n:].any()
+        elif name == "region_filter_batched":
+            anc, off, conf = a[0], a[1], a[2]
+            assert tuple(anc.shape) == (fh * fw * 15, 4) and tuple(off.shape) == (2 * B, fh * fw * 15, 4) and tuple(out[0].shape) == (2 * B, R, 4)
+            for f in range(2 * B):
+                n = int(out[3][f])
+                assert 0 < n <= R and not out[0][f, n:].any()
+                single = saved["region_filter"](anc, off[f].contiguous(), conf[f].contiguous(), 0.3, R, 0.5)
+                assert torch.equal(single[0], out[0][f]) and int(single[3]) == n
         elif name == "ps_roipool_forward":
             fm, rois, nT, k = a[0], a[1], a[2], a[3]
             assert k == 7 and nT in (31, 4) and tuple(fm.shape) == (nT * 49, fh, fw) and tuple(rois.shape) == (R, 4)
@@ -139,11 +153,11 @@ def test_config4_step_at_size_ops_match_reference_kernels(ref_modules, oracle):
             torch.testing.assert_close(out, ref_roi.roipool_forward(fm, rois, k), rtol=1e-5, atol=1e-5, equal_nan=True)
         elif name == "pointwise_correlation_levels_forward":
             f0, f1 = a[0], a[1]
-            assert [tuple(x.shape) for x in f0] == [(1, 512, fh, fw), (1, 1024, fh, fw), (1, 2048, fh, fw)]   # correlation_tracker.py:57-61
+            assert [tuple(x.shape) for x in f0] == [(PB, 512, fh, fw), (PB, 1024, fh, fw), (PB, 2048, fh, fw)]   # correlation_tracker.py:57-61
             buf = out
-            assert tuple(buf.shape) == (1, 3 * cells + 2 * 512, fh, fw)
+            assert tuple(buf.shape) == (PB, 3 * cells + 2 * 512, fh, fw)
             for l, (x0, x1) in enumerate(zip(f0, f1)):
-                want = ref_corr.pointwise_correlation_forward(x0, x1, 8, 1).reshape(1, fh, fw, cells).permute(0, 3, 1, 2)
+                want = ref_corr.pointwise_correlation_forward(x0, x1, 8, 1).reshape(PB, fh, fw, cells).permute(0, 3, 1, 2)
                 got = buf[:, 2 * 512 + l * cells: 2 * 512 + (l + 1) * cells]
                 # the 1024 / 2048-channel levels split their channels over workgroups: f32 rounding of a C-term sum
                 torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))

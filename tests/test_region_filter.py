@@ -92,6 +92,27 @@ def _check_every_nms_decision(confs, boxes, thr, k, iou, dev_keep, dev_conf, tol
     assert marginal <= max_marginal, f"{marginal} decisions sat within {tol} of the threshold: not credible"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [300, 3000], ids=["fused", "mask+nms"])
+def test_batched_frames_equal_single_calls(k):
+    """d2t_region_filter_batched_f32: the N frames of a step in one call; frame f's slices must be the single-frame call's
+    results bit for bit (same kernels, blockIdx.z = frame)."""
+    from detect_to_track.models import _ext
+    rng = np.random.default_rng(11)
+    anchors = _anchors(38, 63, rng)
+    A, N = len(anchors), 4
+    offsets = (rng.standard_normal((N, A, 4)) * 0.5 * [0.5, 0.5, 0.3, 0.3]).astype(np.float32)
+    confs = rng.random((N, A)).astype(np.float32)
+    confs[3] = 0.1                                                     # a frame with nothing above the threshold
+    ta, to, tc = (torch.from_numpy(x).to(DEV) for x in (anchors, offsets, confs))
+    bb, bc, bi, bn = _ext.region_filter_batched(ta, to, tc, 0.3, k, 0.5)
+    assert bb.shape == (N, k, 4) and bn.shape == (N,)
+    for f in range(N):
+        sb, sc, si, sn = _ext.region_filter(ta, to[f].contiguous(), tc[f].contiguous(), 0.3, k, 0.5)
+        assert torch.equal(bb[f], sb) and torch.equal(bc[f], sc) and torch.equal(bi[f], si) and int(bn[f]) == int(sn)
+    assert int(bn[3]) == 0 and int(bn[0]) > 0
+
+
 def test_nms_decision_checker_bites():
     """The checker itself (CPU): it accepts the numpy pipeline's own result and rejects a list with one box wrongly dropped,
     one wrongly kept, two swapped, or one from below the top-k cut."""
