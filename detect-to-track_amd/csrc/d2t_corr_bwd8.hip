@@ -268,7 +268,8 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     }
 
     // ---- prologue: ring[0] <- G(0) (first: load -> LDS -> barrier -> fragment is the longest chain), S pieces of
-    // super-step 0, registers <- G(1)
+    // super-step 0, registers <- G(1).  (Round 4, measured and dropped: the S pieces issued in front of the descriptor
+    // arithmetic, so that their HBM round trip runs under it -- 70.5 us either way in tools/ab.sh, and 6 more spills.)
     g_load_all(0);
 #pragma unroll
     for (int q = 0; q < KB_SS; ++q)

@@ -23,6 +23,31 @@ from . import _native
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 
+# Leaving the tuned envelope is not silent: the first call of each kind says so once (measured on an MI355X at B = 8, C = 256,
+# 38 x 63 / R = 300, C = 1024: tools/envelope_cost.py, profiles/r04_d_envelope_cost.jsonl).  float64 runs the type-generic
+# kernels by design (the reference's gradcheck tests) and is not reported.
+_ENVELOPE_WARNED = set()
+
+
+def _outside_envelope(kind: str, why: str, factor: str) -> None:
+    if kind in _ENVELOPE_WARNED:
+        return
+    _ENVELOPE_WARNED.add(kind)
+    import warnings
+    warnings.warn(f"detect_to_track {kind}: {why} is outside the gfx950-tuned kernels' envelope; the type-generic kernels run "
+                  f"instead (same results, about {factor} slower at the model's shapes)", RuntimeWarning, stacklevel=3)
+
+
+def _check_corr_envelope(x: Tensor, d_max: int, stride: int, impl: int) -> None:
+    if x.dtype == torch.float32 and impl == _native.IMPL_AUTO and x.numel() and (d_max != 8 or stride != 1 or x.shape[-1] < 20):
+        _outside_envelope("PointwiseCorrelation", f"d_max = {d_max}, stride = {stride}, W = {x.shape[-1]} (tuned: d_max = 8, stride 1, W >= 20)",
+                          "15x (forward) / 35-90x (backward)")
+
+
+def _check_pool_envelope(kind: str, x: Tensor, k: int, impl: int) -> None:
+    if x.dtype == torch.float32 and impl == _native.IMPL_AUTO and x.numel() and k != 7:
+        _outside_envelope(kind, f"r_hw = {k} (tuned: 7)", "5x (forward) / 16-32x (backward)")
+
 
 def _check_input(x: Tensor, name: str) -> None:
     if not isinstance(x, Tensor):
@@ -72,6 +97,7 @@ def pointwise_correlation_forward(FM0: Tensor, FM1: Tensor, d_max: int, stride: 
     if FM0.dim() != 4 or FM1.shape != FM0.shape:
         raise RuntimeError(f"FM0 and FM1 must both be (B, C, H, W); got {tuple(FM0.shape)} and {tuple(FM1.shape)}")
     d_max, stride = int(d_max), int(stride)
+    _check_corr_envelope(FM0, d_max, stride, impl)
     B, C, H, W = FM0.shape
     cw = 2 * d_max + 1
     with torch.cuda.device(FM0.device):
@@ -199,6 +225,7 @@ def roipool_forward(FM: Tensor, rois: Tensor, r_hw: int, impl: int = _native.IMP
     if FM.dim() != 3:
         raise RuntimeError(f"FM must be (C, H, W), got {tuple(FM.shape)}")
     r_hw = int(r_hw)
+    _check_pool_envelope("ROIPool", FM, r_hw, impl)
     C, H, W = FM.shape
     with torch.cuda.device(FM.device):
         out = torch.empty((R, C, r_hw, r_hw), dtype=FM.dtype, device=FM.device)
@@ -236,6 +263,7 @@ def ps_roipool_forward(FM: Tensor, rois: Tensor, n_targets: int, r_hw: int, impl
         # the reference's launcher never checks this (ps_roipool_cuda.cu:144-174) and would read
         # out of bounds; the Function raises ValueError before reaching here (ps_roipool.py:44-49)
         raise RuntimeError(f"FM must be ({n_targets * r_hw * r_hw}, H, W), got {tuple(FM.shape)}")
+    _check_pool_envelope("PSROIPool", FM, r_hw, impl)
     _, H, W = FM.shape
     with torch.cuda.device(FM.device):
         out = torch.empty((R, n_targets, r_hw, r_hw), dtype=FM.dtype, device=FM.device)

@@ -65,7 +65,16 @@ enum {
 int         d2t_version(void);
 const char* d2t_error_string(int code);
 
-/* Implementation selector of the f32 entry points (per call, no global state):
+/* The tuned envelope and what leaving it costs.  The gfx950-tuned kernels cover what the reference model uses
+ * (cfg/default.yaml:48,50: D_MAX 8, K 7; correlation_tracker.py:26: stride 1): correlation d_max = 8, stride 1, W >= 20;
+ * pooling k = 7; float32.  Everything else -- and all of float64 -- runs type-generic kernels (one thread per output
+ * element, reference order): same results, measured on an MI355X (tools/envelope_cost.py, us forward / backward):
+ *   correlation B=8 C=256 38x63   tuned 46 / 73     d_max=7: 668 / 6,743     stride 2: 787 / 2,539     f64: 1,230 / 11,216
+ *   ROIPool R=300 C=1024 38x63    tuned 31 / 72     k=6: 168 / 2,346         f64: 270 / 3,105
+ *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 510            f64: 25 / 640
+ * (the Python wrappers warn once when a float32 call leaves the envelope under D2T_IMPL_AUTO).
+ *
+ * Implementation selector of the f32 entry points (per call, no global state):
  *   D2T_IMPL_AUTO    the tuned gfx950 path when its preconditions hold and it is the faster one
  *                    (ROIPool forward with fewer than 32 RoIs takes the generic kernel), else generic
  *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)
