@@ -141,6 +141,12 @@ typedef std::integral_constant<int, 5> I5;
 #ifndef D2T_EXP_GCO
 #define D2T_EXP_GCO 1
 #endif
+#ifndef D2T_EXP_SWZ
+#define D2T_EXP_SWZ 0
+#endif
+#ifndef D2T_EXP_PRIO
+#define D2T_EXP_PRIO 0
+#endif
 #ifndef S8_ABL
 #define S8_ABL 0      // timing ablations (lab builds only, results are wrong): 1 no S reloads, 2 no tile stores, 4 no G loads, 8 no ring writes, 32 role 0 alone, 64 role 1 alone
 #endif
@@ -220,10 +226,14 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     auto g_put = [&](float* rb, int k, const f32x4& raw) {
         const f32x4 v = quad8_fix(raw, qd[k].info);
         const int e = GCO ? er[k] : gtid + k * GT;
-        if (!role) { reinterpret_cast<f32x4*>(rb)[e] = v; return; }
+        // D2T_EXP_SWZ: inside its 64-quad block the quad of lane l = (gg, pixel) sits at position l ^ (gg & 3) -- the reader's
+        // ds_read_b128 stays conflict-free (an XOR below 4 permutes inside aligned groups of four quads) and the role-0
+        // producer, whose consecutive lanes write the pieces (k-block, gg) of ONE pixel, spreads over four bank groups
+        const int f = D2T_EXP_SWZ ? (e >> 4) & 3 : 0;
+        if (!role) { reinterpret_cast<f32x4*>(rb)[e ^ f] = v; return; }
         // role 1: component lo2 = s of the quads of lanes (tpi*4 + c, gg), c = 0..3
         float* w = rb + (((e & ~63) + (lane & 0x3c)) << 2) + (lane & 3);
-        w[0] = v[0]; w[4] = v[1]; w[8] = v[2]; w[12] = v[3];
+        w[(0 ^ f) << 2] = v[0]; w[(1 ^ f) << 2] = v[1]; w[(2 ^ f) << 2] = v[2]; w[(3 ^ f) << 2] = v[3];
     };
     f32x4 gn[S8_NQ];
     auto g_load_all = [&](int ss) {
@@ -279,7 +289,7 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     g_load_all(1);
     lds_barrier();
 
-    const f32x4* lane_ring = reinterpret_cast<const f32x4*>(&ring[0][0]) + lane;
+    const f32x4* lane_ring = reinterpret_cast<const f32x4*>(&ring[0][0]) + (D2T_EXP_SWZ ? lane ^ (g & 3) : lane);
     f32x4 bvP[NACT], bvQ[NACT];
     auto b_fetch = [&](f32x4 (&bv)[NACT], int buf, int q, auto lo_c, auto hi_c) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
@@ -379,6 +389,11 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     };
 
     b_fetch(bvP, 0, 0, I2{}, I5{});
+#if D2T_EXP_PRIO
+    // the second-dispatched half of the workgroup loses the arbitration for the matrix pipe and the vector issue on every
+    // super-step (waves 0-3 wait 3.6 k cycles per super-step at the barrier, waves 4-7 0.3 k): static priority for it
+    if (wave >= S8_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     D2T_WCLK(w_t1); D2T_WRT(w_r1);
     // tiles_i >= 5 (host-checked): two leading, tiles_i - 4 full, two trailing super-steps
     super_step(0, bvP, bvQ, I2{}, I5{}, I1{}, I5{});
