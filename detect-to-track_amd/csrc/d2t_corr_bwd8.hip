@@ -142,7 +142,7 @@ typedef std::integral_constant<int, 5> I5;
 #define D2T_EXP_GCO 1
 #endif
 #ifndef D2T_EXP_SWZ
-#define D2T_EXP_SWZ 0
+#define D2T_EXP_SWZ 1      // ring swizzle (round 4: 70.4 -> 70.2 us in two A/B rounds, LDS bank conflicts of the memory-order producer gone)
 #endif
 #ifndef D2T_EXP_PRIO
 #define D2T_EXP_PRIO 0
@@ -391,7 +391,8 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
     b_fetch(bvP, 0, 0, I2{}, I5{});
 #if D2T_EXP_PRIO
     // the second-dispatched half of the workgroup loses the arbitration for the matrix pipe and the vector issue on every
-    // super-step (waves 0-3 wait 3.6 k cycles per super-step at the barrier, waves 4-7 0.3 k): static priority for it
+    // super-step (waves 0-3 wait 3.6 k cycles per super-step at the barrier, waves 4-7 0.3 k): static priority for it.
+    // Measured (round 4, tools/ab.sh, profiles/r04_d_ab_bwd_setprio.txt): 70.9 us against 70.2 without -- off.
     if (wave >= S8_WAVES / 2) __builtin_amdgcn_s_setprio(1);
 #endif
     D2T_WCLK(w_t1); D2T_WRT(w_r1);

@@ -21,9 +21,13 @@ for it in range(N):
         g0, g1 = _ext.pointwise_correlation_backward(go, fm0, fm1, 8, 1, GENERIC)
         m0, m1 = _ext.pointwise_correlation_backward(go.abs(), fm0.abs(), fm1.abs(), 8, 1, GENERIC)
         assert bool(((t0 - g0).abs() <= 4e-6 * m0 + 1e-7).all()) and bool(((t1 - g1).abs() <= 4e-6 * m1 + 1e-7).all())
-        if H >= 17:                                                  # the bf16x3 backward (opt-in), same bar
-            s0, s1 = _ext.pointwise_correlation_backward(go, fm0, fm1, 8, 1, 4)
-            assert bool(((s0 - g0).abs() <= 4e-6 * m0 + 1e-7).all()) and bool(((s1 - g1).abs() <= 4e-6 * m1 + 1e-7).all()), "bf16x3"
+        if H >= 17:                                                  # the bf16x3 backward (opt-in) and the two 8-wave kernels demanded, same bar
+            for impl, name in ((4, "bf16x3"), (6, "strips 8 pixels wide"), (7, "strips 4 pixels wide")):
+                s0, s1 = _ext.pointwise_correlation_backward(go, fm0, fm1, 8, 1, impl)
+                assert bool(((s0 - g0).abs() <= 4e-6 * m0 + 1e-7).all()) and bool(((s1 - g1).abs() <= 4e-6 * m1 + 1e-7).all()), name
+        fa = _ext.pointwise_correlation_forward(fm0, fm1, 8, 1, 5)   # D2T_IMPL_FAST: may split channels (same terms, other association)
+        mf = _ext.pointwise_correlation_forward(fm0.abs(), fm1.abs(), 8, 1, GENERIC)
+        assert bool(((fa - b).abs() <= 4e-6 * mf + 1e-7).all()), "fast forward"
     except Exception as e:
         bad += 1; print("CORR FAIL", (B, C, H, W), str(e)[:200], flush=True)
     if it % 20 == 19: print(f"{it + 1} cases, {bad} failures", flush=True)
