@@ -95,6 +95,9 @@ struct BwdLevels { const float* gout[MAXLV]; const float* fm0[MAXLV]; const floa
 // tile-group) tasks.  At B=8, 38x63 the grid is 8 x 16 x 2 = 256 workgroups of exactly 5 tiles:
 // one per CU.  Arithmetic is unchanged (ascending-channel MFMA chain): bit-identical results.
 // ------------------------------------------------------------------------------------
+#ifndef D2T_EXP_EPI
+#define D2T_EXP_EPI 0      // tile-by-tile epilogue (round 4): measured 50.1 us against 47.5 us for the one-barrier form -- off
+#endif
 constexpr int SG_NU = 5;                            // p-tiles per segment
 constexpr int SG_WAVES = 15;                        // <= 30 (tile, tile-group) tasks, at most two per wave
 constexpr int SG_THREADS = SG_WAVES * 64;
@@ -343,20 +346,29 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     // structural zeros (cj = 16, ci = 16, displaced column outside the map) of the rows it covers.
     // Rows of the 17 x 17 map whose displaced row lies outside the tile's window (ci = 16 of the
     // tile's last pixel row; rows cut off by the map edge) are zero-filled here.
-    for (int e = tid; e < nu * 16 * CW; e += SG_THREADS) {
-        const int p = e / CW, ci = e - p * CW, t = p >> 4, gg = (p >> 2) & 3;
-        const int u = u0 + t;
-        const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;
-        const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
-        const int rho = 4 * u + gg - DT + ci;
-        if (rho < wa || rho >= wb) {
-            float* row = smem + p * CELLS + ci * CW;
+    // D2T_EXP_EPI (lab switch, off): tile by tile -- the stores of tile t issued as soon as its 16 x 17 x 17 block is staged,
+    // so that the 22 MB all workgroups of the chip write at the same moment start to drain while the later tiles are still
+    // scattered (nu barriers instead of one).  Measured in the alternating step (tools/ab.sh, three rounds,
+    // profiles/r04_d_ab_fwd_epilogue_by_tile.txt): 50.1 / 50.1 / 50.2 us against 47.8 / 47.2 / 47.5 -- the extra barriers and
+    // the five small store bursts cost more than the earlier start saves.
+    const int nj = W - j0 < TP ? W - j0 : TP;
+    const int run_ = nj * CELLS, run4 = run_ >> 2;                   // floats / whole float4s per pixel row
+    const int prs = (H - 4 * u0 < 4 * nu ? H - 4 * u0 : 4 * nu);     // pixel rows that exist
+    auto zero_rows = [&](int t_lo, int t_hi) {
+        for (int e = t_lo * 16 * CW + tid; e < t_hi * 16 * CW; e += SG_THREADS) {
+            const int p = e / CW, ci = e - p * CW, t = p >> 4, gg = (p >> 2) & 3;
+            const int u = u0 + t;
+            const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;
+            const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
+            const int rho = 4 * u + gg - DT + ci;
+            if (rho < wa || rho >= wb) {
+                float* row = smem + p * CELLS + ci * CW;
 #pragma unroll
-            for (int cj = 0; cj < CW; ++cj) row[cj] = 0.f;
+                for (int cj = 0; cj < CW; ++cj) row[cj] = 0.f;
+            }
         }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    };
+    auto scatter = [&](int k) {
         const int gi = 16 * t_T[k] + n;
         if (t_on[k] && gi < t_ng[k]) {
             const int u = u0 + t_tile[k];
@@ -377,14 +389,44 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
                 }
             }
         }
+    };
+    auto store_rows = [&](int pr_lo, int pr_hi) {                    // pixel rows [pr_lo, pr_hi) of the segment, reference layout
+        for (int e = pr_lo * run4 + tid; e < pr_hi * run4; e += SG_THREADS) {
+            const int pr = e / run4, q = e - pr * run4;
+            const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
+                                                   ro, off, 0, 0);   // plain write-back stores.  Round 1 used sc1 (write-through: 63 -> 51 us
+                                                                     // then); with the ring-of-3 schedule plain stores are 0.9 us faster (A/B, round 2)
+        }
+        const int tail = run_ - 4 * run4;                            // 0..3 floats per pixel row (nj < 4)
+        for (int e = pr_lo * tail + tid; e < pr_hi * tail; e += SG_THREADS) {
+            const int pr = e / tail, q = 4 * run4 + (e - pr * tail);
+            outb[((size_t)(4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
+        }
+    };
+#if D2T_EXP_EPI
+    if (lay.cs == 1) {
+        for (int t = 0; t < nu; ++t) {                               // wave-uniform trip count
+            zero_rows(t, t + 1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (t_tile[k] == t) scatter(k);                      // wave-uniform
+            __syncthreads();
+            const int lo = 4 * t < prs ? 4 * t : prs, hi = 4 * t + 4 < prs ? 4 * t + 4 : prs;
+            store_rows(lo, hi);
+        }
+        D2T_STAMP(4);
+        D2T_STAMP(5);
+        return;
     }
+#endif
+    zero_rows(0, nu);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) scatter(k);
     __syncthreads();
     D2T_STAMP(4);
-    // 16-byte write-through stores (dword-aligned addresses): a pixel row of the strip is nj*289
-    // contiguous floats in out and starts 16-byte aligned in the LDS image
-    const int nj = W - j0 < TP ? W - j0 : TP;
-    const int run_ = nj * CELLS, run4 = run_ >> 2;                   // floats / whole float4s per pixel row
-    const int prs = (H - 4 * u0 < 4 * nu ? H - 4 * u0 : 4 * nu);     // pixel rows that exist
+    // 16-byte stores (dword-aligned addresses): a pixel row of the strip is nj*289 contiguous floats in out and starts
+    // 16-byte aligned in the LDS image
     if (lay.cs != 1) {
         // channel-major: cell c of pixel row pr is the 16-byte piece out[c][4*u0+pr][j0..j0+3]; consecutive
         // threads take consecutive cells (consecutive LDS words, pieces H*W*4 bytes apart in memory)
@@ -397,18 +439,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
         D2T_STAMP(5);
         return;
     }
-    for (int e = tid; e < prs * run4; e += SG_THREADS) {
-        const int pr = e / run4, q = e - pr * run4;
-        const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
-                                               ro, off, 0, 0);     // plain write-back stores.  Round 1 used sc1 (write-through: 63 -> 51 us
-                                                                   // then); with the ring-of-3 schedule plain stores are 0.9 us faster (A/B, round 2)
-    }
-    const int tail = run_ - 4 * run4;                                // 0..3 floats per pixel row (nj < 4)
-    for (int e = tid; e < prs * tail; e += SG_THREADS) {
-        const int pr = e / tail, q = 4 * run4 + (e - pr * tail);
-        outb[((size_t)(4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
-    }
+    store_rows(0, prs);
     D2T_STAMP(5);
 #ifdef D2T_LAB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the stores have been acknowledged
