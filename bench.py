@@ -287,9 +287,14 @@ def run(args, device):
     rank, world, _ = rank_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: main() starts the ranks itself when launched bare")
-    if world > 1:
+    # --force-dist 1: take the process-group path at world size 1 too (under torch.distributed.run --nproc-per-node 1): the
+    # RCCL group is created and every barrier / MAX / SUM below runs as a real collective on GPU tensors -- the only way to
+    # exercise HipDevice.init_process_group and the collectives' stream semantics on a box with ONE GPU.
+    dist_on = world > 1 or bool(getattr(args, "force_dist", 0))
+    if dist_on:
         device.init_process_group()
-    ranks_seen = int(round(sum_over_ranks(1.0, world, device.reduce_device())))
+    nred = world if world > 1 else (2 if dist_on else 1)               # > 1 makes the helpers below reduce
+    ranks_seen = int(round(sum_over_ranks(1.0, nred, device.reduce_device())))
 
     cfg = WORKLOADS[args.workload]
     B, C, H, W = (cfg[k] for k in "BCHW")
@@ -299,7 +304,7 @@ def run(args, device):
     device.setup(cfg, n_sets, seed=rank)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         device.synchronize()
 
@@ -333,7 +338,7 @@ def run(args, device):
         device.fwd(order[i])
         device.bwd(order[i])
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, world, device.reduce_device())
+    elapsed = max_over_ranks(time.perf_counter() - t0, nred, device.reduce_device())
     # The per-kernel figures: the SAME K steps once more, with a HIP event in front of every kernel and one behind the
     # last (2 K + 1 records; a step's closing event is the next one's opening event).  kernels[] / roofline = the event
     # intervals; they add up to the wall time of THIS pass (asserted below), which is longer than the metric's: an event
@@ -354,7 +359,7 @@ def run(args, device):
     elapsed_ev = time.perf_counter() - t0
     us_fwd = [device.elapsed_ms(ev[2 * i], ev[2 * i + 1]) * 1e3 for i in range(K)]
     us_bwd = [device.elapsed_ms(ev[2 * i + 1], ev[2 * i + 2]) * 1e3 for i in range(K)]
-    elapsed_ev = max_over_ranks(elapsed_ev, world, device.reduce_device())
+    elapsed_ev = max_over_ranks(elapsed_ev, nred, device.reduce_device())
 
     # Extra, NOT the metric (--graph 1): the same K steps replayed as one HIP graph -- what a training loop that captures
     # its steps gets (no event records, no host work between the kernels).  The C-ABI calls are asynchronous, allocate
@@ -380,7 +385,7 @@ def run(args, device):
             device.synchronize()
         # every rank takes the same path through the collectives below: a rank whose capture failed must not leave
         # the others waiting in a barrier (MAX over ranks of "failed")
-        failed = max_over_ranks(1.0 if err else 0.0, world, device.reduce_device()) > 0.0
+        failed = max_over_ranks(1.0 if err else 0.0, nred, device.reduce_device()) > 0.0
         if failed:
             graph_replay = {"error": err or "graph capture failed on another rank"}
         else:
@@ -388,7 +393,7 @@ def run(args, device):
             t0 = time.perf_counter()
             device.replay(graph)
             barrier()
-            eg = max_over_ranks(time.perf_counter() - t0, world, device.reduce_device())
+            eg = max_over_ranks(time.perf_counter() - t0, nred, device.reduce_device())
             graph_replay = {"ms_per_step": eg / K * 1e3, "value": whole_job_value(cnt["vox"], world, K, eg) / 1e9,
                             "note": "one hipGraph replay of the same K steps; not the metric"}
 
@@ -408,14 +413,14 @@ def run(args, device):
                 device.fwd(z)
                 device.bwd_as(z, impl)
             barrier()
-            return max_over_ranks(time.perf_counter() - t0, world, device.reduce_device())
+            return max_over_ranks(time.perf_counter() - t0, nred, device.reduce_device())
         err = None
         try:
             device.bwd_as(order[0], 4)                           # does this build / shape have the kernel at all?
             device.synchronize()
         except Exception as e:
             err = f"{type(e).__name__}: {str(e)[:160]}"
-        if max_over_ranks(1.0 if err else 0.0, world, device.reduce_device()) > 0.0:
+        if max_over_ranks(1.0 if err else 0.0, nred, device.reduce_device()) > 0.0:
             bf16x3 = {"error": err or "failed on another rank"}
         else:
             e0, e4 = plain_pass(0), plain_pass(4)
@@ -496,6 +501,7 @@ def run(args, device):
             "pct_hbm_roofline_fwd": 100 * kernels[0]["hbm"]["frac"],
             "pct_hbm_roofline_bwd": 100 * kernels[1]["hbm"]["frac"],
             "settle_steps": settle_steps, "settle_ms": settle_ms, "ranks_seen": ranks_seen,
+            "process_group": getattr(device, "backend", None) if dist_on else None,
             "event_pass": {"ms_per_step": ms_ev, "records_per_step": 2, "event_record_overhead_us": record_us,
                            "host_ms_per_step_minus_device": ms_ev - t_dev},
             "graph_replay": graph_replay,
@@ -510,7 +516,7 @@ def run(args, device):
             line["cpu_baseline"] = cpu_baseline(cfg, cnt)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     return dict(settle_steps=settle_steps, ranks_seen=ranks_seen)
@@ -528,6 +534,8 @@ def parse_args(argv=None):
     ap.add_argument("--graph", type=int, default=1, help="1: also replay the K steps as one HIP graph (reported beside the metric)")
     ap.add_argument("--extras", type=int, default=1, help="1: also time the K steps with the opt-in bf16x3 backward (reported beside the metric)")
     ap.add_argument("--ops", type=int, default=1, help="1: also time every other op / shape of the path (ops[] in the line, rank 0, ~3 s)")
+    ap.add_argument("--force-dist", type=int, default=0, help="1: create the process group and run the collectives at world size 1 too "
+                    "(launch under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--settle-ms", type=float, default=SETTLE_MS, help="untimed steps until this much wall time has passed (clock settling)")
     return ap.parse_args(argv)
 

@@ -62,6 +62,8 @@ def parse_args(argv=None):
     p.add_argument("--gpus", type=int, default=1, help="ranks (BASELINE config 5); launch with torch.distributed.run, one rank per GPU")
     p.add_argument("--bucket-mb", type=float, default=64.0, help="gradient all-reduce bucket size")
     p.add_argument("--backend", default="nccl", help="nccl = RCCL (one GPU per rank); gloo lets several ranks rehearse on ONE GPU")
+    p.add_argument("--force-dist", action="store_true", help="create the process group, the gradient buckets and their all-reduces at world size 1 "
+                   "too (under torch.distributed.run --nproc-per-node 1): exercises the RCCL path on a box with one GPU")
     p.add_argument("--per-pair", action="store_true", help="the reference's Python loop over the pairs of a minibatch (B = 1 op calls) instead of "
                    "one batched pass (training.py: forward_loss_pairs)")
     p.add_argument("--exact-tracker", action="store_true", help="keep the tracker's correlation forward bit-identical to the reference (default dispatch) "
@@ -122,8 +124,9 @@ def main(argv=None):
     from detect_to_track.models import DetectTrackModule, _ext
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    dist_on = world > 1 or args.force_dist                                         # --force-dist: the RCCL path at world size 1 (one-GPU rehearsal)
     buckets = None
-    if world > 1:                                                                  # config 5: weak scaling, B pairs per GPU,
+    if dist_on:                                                                    # config 5: weak scaling, B pairs per GPU,
         import torch.distributed as dist                                            # gradients averaged over RCCL / xGMI
         from detect_to_track.data_parallel import GradientBuckets
         if args.backend == "nccl":
@@ -151,7 +154,7 @@ def main(argv=None):
     # steps, and non-finite feature maps would put the ops on their (slow, cold) non-finite repair paths
     optim = torch.optim.SGD(params, lr=args.lr, weight_decay=1e-4, momentum=0.9)
     coefs = torch.tensor([1.0, 1.0, 1.0, 1.0, 1.0e-4], device=dev)           # cfg COEFS
-    if world > 1:
+    if dist_on:
         buckets = GradientBuckets(params, bucket_mb=args.bucket_mb)
     torch.manual_seed(1 + rank)                                                    # every rank its own frames
 
@@ -193,7 +196,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         if rank == 0:
             print(f"[bench_model] warmup step {w}: {time.time() - t:.1f} s", file=sys.stderr, flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     timer.enabled = True
@@ -206,7 +209,7 @@ def main(argv=None):
     s1.record()
     torch.cuda.synchronize()
     step_ms = s0.elapsed_time(s1) / args.steps
-    if world > 1:                                                                  # the slowest rank defines the step
+    if dist_on:                                                                    # the slowest rank defines the step
         t = torch.tensor([step_ms], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         step_ms = float(t.item())
@@ -235,7 +238,7 @@ def main(argv=None):
     line = {
         "bench": "DetectTrack training step (BASELINE config %d)" % (4 if world == 1 else 5), "n_gpus": world, "scaling": "weak",
         "parallelism": f"dp{world}" if world > 1 else "single", "dtype": "f32", "data": "synthetic",
-        "weights": "random", "pairs_batched": not args.per_pair, "tracker_fast_forward": not args.exact_tracker, "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find),
+        "weights": "random", "process_group": args.backend if dist_on else None, "gradient_buckets": buckets is not None, "pairs_batched": not args.per_pair, "tracker_fast_forward": not args.exact_tracker, "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find),
         "config": {"workload": f"detecttrack_{args.backbone}_B{B}pairs_3x{H}x{W}", "pairs": B, "frame": [3, H, W],
                    "c4": [fh, fw], "regions_per_frame": R, "tracked_boxes": Rt, "anchors": n_anchor},
         "ms_per_step": step_ms, "pairs_per_s": world * B / step_ms * 1e3, "pairs_per_gpu": B, "finite": finite, "max_abs_activation": amax,
@@ -248,7 +251,7 @@ def main(argv=None):
     }
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
