@@ -112,6 +112,11 @@ def test_bench_rank_skeleton_under_torchrun():
     assert d["event_pass"]["records_per_step"] == 2
     assert d["timing"]["value"].startswith("wall time of K eager steps") and d["graph_replay"]["ms_per_step"] >= 2 * (2 + 3) * 0.95
     assert "cpu_baseline" not in d                          # rank 0 at N = 1 only
+    # round-4 fields: the third roof per kernel (profiles/ta_roof.json), the op table (device layers without one: null), the backend
+    for k in d["kernels"]:
+        ta = k["roofline_ta"]
+        assert ta is None or (ta["lines"] > 0 and ta["peak"] > 0 and abs(ta["frac"] - ta["achieved"] / ta["peak"]) < 1e-9)
+    assert d["ops"] is None and d["process_group"] == "gloo"
     assert p.stderr.count("stub rank") == 2
 
 
