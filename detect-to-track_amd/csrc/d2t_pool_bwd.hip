@@ -34,6 +34,7 @@
 namespace d2t { namespace tuned {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KT = 7;                         // r_hw the tuned pooling kernels are built for
 constexpr int KK = KT * KT;
@@ -288,8 +289,13 @@ __device__ __forceinline__ bool pool_nonfinite4(const f32x4& d)
     return !(m <= 3.4028234663852886e38f) || d[0] != d[0] || d[1] != d[1] || d[2] != d[2] || d[3] != d[3];
 }
 struct RmSlot { int goff; int jb; float scale; int pad; };           // 16 bytes
-// every bin row of a RoI can contain a given map row (RoIs lower than 7 pixels): 49 slots per RoI and row
-inline int rm_cap(int R) { return (R * KK + 3) & ~3; }
+// every bin row of a RoI can contain a given map row (RoIs lower than 7 pixels): 7 pairs (RoI, bin row) per RoI and map row,
+// each written as EIGHT entries = two k-steps: slots j = 0, 2, 4, 6, then j = 1, 3, 5 and a zero-scale pad.  Lane group g of the
+// GEMM kernel then fetches slots 2g and 2g+1 of a pair with ONE 8-byte load per channel (the pair's 28-byte record of
+// gradOut = one cache line touched once) and uses its two components in the two k-steps -- round 4; before, a pair's
+// seven slots were packed 4 + 3 into k-steps that straddled pairs and every k-step fetched its 16 lines again.
+constexpr int RM_PS = 8;                                               // list entries per (RoI, bin row) pair
+inline int rm_cap(int R) { return R * KT * RM_PS; }
 static size_t rm_lists_bytes(int R, int H) { return align256((size_t)H * rm_cap(R) * sizeof(RmSlot)) + align256((size_t)H * sizeof(int)); }
 
 __global__ void __launch_bounds__(256)
@@ -331,22 +337,22 @@ k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, in
         for (int i = 0; i < KT; ++i)
             if (mk & (1 << i)) pairs[pos++] = (unsigned)tid | (unsigned)i << 8 | (unsigned)hgt[i] << 16;
         __syncthreads();
-        for (int sidx = tid; sidx < npairs * KT; sidx += 256) {
-            const int p = sidx / KT, j = sidx - p * KT;
+        for (int sidx = tid; sidx < npairs * RM_PS; sidx += 256) {
+            const int p = sidx / RM_PS, q = sidx - p * RM_PS;
+            const int j = q < 4 ? 2 * q : 2 * (q - 4) + 1;           // entry q of a pair: j = 0, 2, 4, 6, 1, 3, 5, (7 = pad)
             const unsigned pr = pairs[p];
             const int rl = pr & 255, i = (pr >> 8) & 7, h = pr >> 16;
-            const int jb = colb[rl][j], n = h * ((jb >> 16) - (jb & 0xffff));
+            const int jb = j < KT ? colb[rl][j] : 0, n = j < KT ? h * ((jb >> 16) - (jb & 0xffff)) : 0;
             RmSlot e;
-            e.goff = (r0 + rl) * C * KK + i * KT + j;                // + channel * 49
+            e.goff = (r0 + rl) * C * KK + i * KT + (j < KT ? j : KT - 1);   // + channel * 49 (the pad points at slot 6: never dereferenced on its own)
             e.jb = jb;
             e.scale = n > 0 ? 1.0f / static_cast<float>(n) : 0.f;
             e.pad = 0;
             out[nslots + sidx] = e;
         }
-        nslots += npairs * KT;
+        nslots += npairs * RM_PS;
     }
-    if (tid < ((4 - (nslots & 3)) & 3)) out[nslots + tid] = RmSlot{0, 0, 0.f, 0};   // zero-scale padding to a multiple of 4
-    const int nks = (nslots + 3) >> 2;
+    const int nks = nslots >> 2;                                      // two k-steps per pair
     if (tid == 0) rownks[y] = nks;
     __syncthreads();                                                 // the row's list is complete (and visible to this workgroup)
     // per k-step (4 slots): which 16-column tiles does any of its slots reach?  Stored in all four `pad`
@@ -373,7 +379,7 @@ constexpr int RG_PF = 4;                      // k-steps of gradOut loads in fli
 template <int XT, int NCT, int NW>
 __global__ void __launch_bounds__(NW * 64)
 k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ rowslots, const int* __restrict__ rownks,
-                   float* __restrict__ gin, int C, int H, int W, int cap, int ncb, int ntasks)
+                   float* __restrict__ gin, int C, int H, int W, int cap, int ncb, int ntasks, unsigned gout_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     RmSlot* list = reinterpret_cast<RmSlot*>(lds_raw);               // [4 * RG_CH]
@@ -381,6 +387,7 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
     constexpr int NACC = NCT * XT, NTHR = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, (unsigned)gout_bytes, 0x00020000);
     // One task per workgroup; more workgroups than fit the chip, so the hardware dispatcher hands the next
     // task to whichever CU frees a slot -- a work queue without the ~3 us per task an atomic counter +
     // broadcast cost when tried.  Tasks are numbered from the MIDDLE rows outwards (mid, mid+1, mid-1, ...):
@@ -390,9 +397,9 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
         const int c0 = (t - p * ncb) * (16 * NCT);
         const RmSlot* sl = rowslots + (size_t)y * cap;
         const int nks = rownks[y];
-        const float* ga[NCT];
+        int gach[NCT];                                                // float offset of this lane's channel record (clamped: never stored)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) ga[ct] = gout + (size_t)(c0 + 16 * ct + n < C ? c0 + 16 * ct + n : C - 1) * KK;   // clamped: never stored
+        for (int ct = 0; ct < NCT; ++ct) gach[ct] = (c0 + 16 * ct + n < C ? c0 + 16 * ct + n : C - 1) * KK;
         f32x4 acc[NCT][XT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -404,40 +411,49 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
             if (k0) __syncthreads();                                 // previous chunk consumed
             for (int e = tid; e < 4 * kc; e += NTHR) list[e] = sl[4 * k0 + e];
             __syncthreads();
-            // wave w takes k-steps w, w+NW, ...; lane (n, g) takes slot 4*ks + g
-            const int mine = (kc - wave + NW - 1) / NW;
-            float av[RG_PF][NCT];
+            // wave w takes PAIRS (two k-steps = the 8 entries of one (RoI, bin row)) w, w+NW, ...; lane (n, g) loads the
+            // pair's slots 2g, 2g+1 of channel n with one 8-byte load (range-checked: slot "7" of the last record of the
+            // tensor lies behind it and reads as 0; its scale is 0 anyway) and multiplies component 0 in the pair's first
+            // k-step (entries 8p + g: even slots) and component 1 in its second (entries 8p + 4 + g: odd slots, pad)
+            const int kp = kc >> 1;                                   // pairs in this chunk
+            const int mine = (kp - wave + NW - 1) / NW;
+            f32x2 av[RG_PF][NCT];
+            auto a_load = [&](int m, int ct) -> f32x2 {
+                const int go = list[8 * (wave + NW * m) + g].goff;
+                return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, (int)((unsigned)(gach[ct] + go) * 4u), 0, 0));
+            };
 #pragma unroll
-            for (int q = 0; q < RG_PF; ++q) {
-                const int go = q < mine ? list[4 * (wave + NW * q) + g].goff : 0;
+            for (int q = 0; q < RG_PF; ++q)
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) av[q][ct] = q < mine ? ga[ct][go] : 0.f;
-            }
+                for (int ct = 0; ct < NCT; ++ct) av[q][ct] = q < mine ? a_load(q, ct) : f32x2{0.f, 0.f};
 #pragma unroll 1
-            // (a straight-line variant -- list padded so that every wave runs full prefetch rounds, loads unconditional --
-            // is what k_ps_bwd_gemm uses, where it gained 6 %; here it measured 92 us against 82 us for this form)
             for (int m0 = 0; m0 < mine; m0 += RG_PF) {
 #pragma unroll
                 for (int q = 0; q < RG_PF; ++q) {
-                    const int m = m0 + q;                            // this wave's m-th k-step of the chunk
-                    const RmSlot e = list[4 * (wave + NW * (m < mine ? m : 0)) + g];
-                    const float sc = m < mine ? e.scale : 0.f;
-                    float a[NCT];
+                    const int m = m0 + q;                            // this wave's m-th pair of the chunk
+                    f32x2 cur[NCT];
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) a[ct] = sc != 0.f ? av[q][ct] * sc : 0.f;
+                    for (int ct = 0; ct < NCT; ++ct) cur[ct] = av[q][ct];
                     const int nxt = m + RG_PF;                       // refill this register slot
-                    const int go = nxt < mine ? list[4 * (wave + NW * nxt) + g].goff : 0;
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) av[q][ct] = nxt < mine ? ga[ct][go] : 0.f;
-                    const int j0 = sc != 0.f ? e.jb & 0xffff : 0, j1 = sc != 0.f ? e.jb >> 16 : 0;
-                    const int tm = m < mine ? __builtin_amdgcn_readfirstlane(e.pad) : 0;   // column tiles this k-step reaches
+                    for (int ct = 0; ct < NCT; ++ct) av[q][ct] = nxt < mine ? a_load(nxt, ct) : f32x2{0.f, 0.f};
 #pragma unroll
-                    for (int x = 0; x < XT; ++x) {                   // B: is its column inside the slot's bin?
-                        if (!(tm & (1 << x))) continue;              // none of the 4 slots reaches this tile: B = 0 (scalar test)
-                        const int col = 16 * x + n;
-                        const float ind = col >= j0 && col < j1 ? 1.f : 0.f;
+                    for (int h = 0; h < 2; ++h) {                    // the pair's two k-steps
+                        const RmSlot e = list[8 * (wave + NW * (m < mine ? m : 0)) + 4 * h + g];
+                        const float sc = m < mine ? e.scale : 0.f;
+                        float a[NCT];
 #pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], ind, acc[ct][x], 0, 0, 0);
+                        for (int ct = 0; ct < NCT; ++ct) a[ct] = sc != 0.f ? cur[ct][h] * sc : 0.f;
+                        const int j0 = sc != 0.f ? e.jb & 0xffff : 0, j1 = sc != 0.f ? e.jb >> 16 : 0;
+                        const int tm = m < mine ? __builtin_amdgcn_readfirstlane(e.pad) : 0;   // column tiles this k-step reaches
+#pragma unroll
+                        for (int x = 0; x < XT; ++x) {               // B: is its column inside the slot's bin?
+                            if (!(tm & (1 << x))) continue;          // none of the 4 slots reaches this tile: B = 0 (scalar test)
+                            const int col = 16 * x + n;
+                            const float ind = col >= j0 && col < j1 ? 1.f : 0.f;
+#pragma unroll
+                            for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], ind, acc[ct][x], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -486,7 +502,8 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
 
 static bool roipool_bwd_mfma_supported(int R, int C, int H, int W, int k)
 {
-    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && W <= 128 && H <= 65535 && 1LL * R * C * KK < 0x7fffffffLL &&
+    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && W <= 128 && H <= 65535 && 1LL * R * C * KK * 4 < 0xfffffff0LL &&   // 32-bit byte offsets into gradOut (buffer loads)
+          
            1LL * H * ((C + 15) / 16) < 0x7fffffffLL && 1LL * H * rm_cap(R) * (long long)sizeof(RmSlot) < 0x7fffffffLL;
 }
 
@@ -518,7 +535,7 @@ static int roipool_bwd_mfma_f32(const float* gout, const float* rois, float* gin
         (void)per_cu;                                                                                          \
         const int nwg = ntasks;            /* one task per workgroup: the dispatcher is the work queue */      \
         hipLaunchKernelGGL((k_roipool_bwd_gemm<XTV, NCTV, NWV>), dim3(nwg), dim3(NWV * 64), lds, st, gout, rowslots, rownks, gin, \
-                           C, H, W, cap, ncb, ntasks);                                                         \
+                           C, H, W, cap, ncb, ntasks, (unsigned)((size_t)R * C * KK * sizeof(float)));                 \
     }
 #define D2T_LAUNCH_GEMM_X(NCTV, NWV) { if (xt <= 4) D2T_LAUNCH_GEMM(4, NCTV, NWV) else if (xt <= 5) D2T_LAUNCH_GEMM(5, NCTV, NWV) else D2T_LAUNCH_GEMM(8, NCTV, NWV) }
     if (cfg == 1) D2T_LAUNCH_GEMM_X(1, 4) else if (cfg == 2) D2T_LAUNCH_GEMM_X(2, 4) else if (cfg == 3) D2T_LAUNCH_GEMM_X(4, 4) else D2T_LAUNCH_GEMM_X(2, 2)
