@@ -142,6 +142,22 @@ def test_bench_bare_form_starts_its_own_ranks():
     assert p.stderr.count("stub rank") == 2                 # both ranks ran to the end
 
 
+@pytest.mark.timeout(300)
+def test_bench_force_dist_world_size_1():
+    """--force-dist 1 under `torch.distributed.run --nproc-per-node 1`: the process group is created and every barrier / MAX /
+    SUM is a real collective although there is one rank (the GPU counterpart is tests/test_rccl_single_gpu.py)."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "tests" / "bench_stub_main.py"), "--gpus", "1", "--force-dist", "1",
+           "--steps", "2", "--warmup", "1", "--settle-ms", "10"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["process_group"] == "gloo" and d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["config"]["global_batch"] == 8
+
+
 def test_bench_parent_never_touches_the_gpu():
     """The bare-form parent must start the ranks BEFORE anything imports torch or initialises HIP (a process that has
     touched the GPU must not spawn / be replaced by ranks on this pool): bench.py imports torch only inside functions
