@@ -53,7 +53,7 @@ inline size_t bins_bytes(int R, int k) { return align_up((size_t)R * k * k * 4 *
 
 extern "C" {
 
-int d2t_version(void) { return 100; }
+int d2t_version(void) { return 104; }   // 1.04: round 4 -- D2T_IMPL_FAST / MFMA_WIDE8 / MFMA_STRIP4, d2t_region_filter_batched_f32
 
 const char* d2t_error_string(int code)
 {
