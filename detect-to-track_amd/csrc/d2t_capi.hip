@@ -73,7 +73,11 @@ size_t d2t_corr_fwd_workspace_bytes(int B, int C, int H, int W, int d, int strid
 }
 size_t d2t_corr_bwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size)
 {
-    return elem_size == 4 ? tuned::corr_bwd_ws_bytes(B, C, H, W, d, stride) : 0;
+    // inside the tuned envelope: what the tuned kernels need (nothing); outside it (and for f64): gradOut re-indexed by displaced
+    // pixel for the blocked kernels of d2t_corr_blocked.hip -- optional: without it the thread-per-element kernels run
+    if (elem_size == 4) return tuned::corr_bwd_supported(B, C, H, W, d, stride) ? tuned::corr_bwd_ws_bytes(B, C, H, W, d, stride)
+                                                                                 : corr_bwd_blocked_ws_bytes<float>(B, C, H, W, d, stride);
+    return elem_size == 8 ? corr_bwd_blocked_ws_bytes<double>(B, C, H, W, d, stride) : 0;
 }
 
 int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int stride,
@@ -89,6 +93,8 @@ int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int 
         return tuned::corr_fwd_f32(fm0, fm1, out, B, C, H, W, d, stride, split ? ws : nullptr, split ? ws_bytes : 0, as_stream(stream));
     }
     if (demands_tuned(impl)) return D2T_EINVAL;     // tuned path demanded but not applicable
+    if (impl != D2T_IMPL_GENERIC && corr_blocked_supported<float>(B, C, H, W, d, stride))
+        return corr_fwd_blocked<float>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));   // same values, bit for bit
     return corr_fwd_generic<float>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -99,6 +105,8 @@ int d2t_corr_fwd_f64(const double* fm0, const double* fm1, double* out, int B, i
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (demands_tuned(impl)) return D2T_EINVAL;
+    // (f64 forward: the four-cells-per-thread kernel measured 1,326 us against 1,230 us for the thread-per-cell one at B=8 C=256 38x63 --
+    // 32-byte vector loads at 8-byte alignment buy nothing; the f64 forward stays on the thread-per-cell kernel)
     return corr_fwd_generic<double>(fm0, fm1, out, B, C, H, W, d, stride, as_stream(stream));
 }
 
@@ -116,18 +124,24 @@ int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, floa
                                    bwd_variant_of(impl));
     }
     if (demands_tuned(impl)) return D2T_EINVAL;
+    if (impl != D2T_IMPL_GENERIC && corr_blocked_supported<float>(B, C, H, W, d, stride) && ws &&
+        ws_bytes >= corr_bwd_blocked_ws_bytes<float>(B, C, H, W, d, stride))
+        return corr_bwd_blocked<float>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, ws, as_stream(stream));
     return corr_bwd_generic<float>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
 }
 
 int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1, double* gfm0, double* gfm1,
                      int B, int C, int H, int W, int d, int stride,
-                     void*, size_t, int impl, d2t_stream_t stream)
+                     void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
     if (demands_tuned(impl)) return D2T_EINVAL;
+    if (impl != D2T_IMPL_GENERIC && corr_blocked_supported<double>(B, C, H, W, d, stride) && ws &&
+        ws_bytes >= corr_bwd_blocked_ws_bytes<double>(B, C, H, W, d, stride))
+        return corr_bwd_blocked<double>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, ws, as_stream(stream));
     return corr_bwd_generic<double>(gout, fm0, fm1, gfm0, gfm1, B, C, H, W, d, stride, as_stream(stream));
 }
 

@@ -29,6 +29,15 @@ template <typename T> int psroipool_bins(const T* rois, int32_t* bounds, int R, 
 int psroipool_channels(int32_t* ch, int nT, int k, hipStream_t st);
 int corr_mask(uint8_t* mask, int H, int W, int d, int s, hipStream_t st);
 
+// ---- correlation outside the tuned envelope, reference layout (d2t_corr_blocked.hip): the generic kernels' arithmetic and order
+// (bit-identical results) with four cells per thread (forward) / gradOut staged in LDS (backward; ws = gradOut re-indexed by
+// displaced pixel)
+template <typename T> bool   corr_blocked_supported(int B, int C, int H, int W, int d, int s);
+template <typename T> size_t corr_bwd_blocked_ws_bytes(int B, int C, int H, int W, int d, int s);
+template <typename T> int    corr_fwd_blocked(const T* fm0, const T* fm1, T* out, int B, int C, int H, int W, int d, int s, hipStream_t st);
+template <typename T> int    corr_bwd_blocked(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1,
+                                              int B, int C, int H, int W, int d, int s, void* ws, hipStream_t st);
+
 // ---- region proposals on the device (d2t_regions.hip): decode + confidence filter + top-k + greedy NMS
 size_t region_filter_ws_bytes(int A, int max_dets);
 int region_max_dets();

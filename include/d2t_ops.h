@@ -11,6 +11,8 @@
  *                           (launcher pointwise_correlation_cuda.cu:178-210)
  *   d2t_corr_bwd_*       <- pointwise_correlation_backward  pointwise_correlation/pointwise_correlation.cpp:36-48
  *                           (launcher pointwise_correlation_cuda.cu:214-249)
+ *                           (d2t_corr_bwd_workspace_bytes is non-zero OUTSIDE the tuned envelope and for f64: with that
+ *                           scratch the blocked kernels run, without it the thread-per-element ones -- same values)
  *   d2t_roipool_fwd_*    <- roipool_forward                 roipool/roipool.cpp:22-32   (roipool_cuda.cu:130-157)
  *   d2t_roipool_bwd_*    <- roipool_backward                roipool/roipool.cpp:35-45   (roipool_cuda.cu:160-190)
  *   d2t_psroipool_fwd_*  <- ps_roipool_forward              ps_roipool/ps_roipool.cpp:23-34 (ps_roipool_cuda.cu:144-174)
@@ -67,9 +69,12 @@ const char* d2t_error_string(int code);
 
 /* The tuned envelope and what leaving it costs.  The gfx950-tuned kernels cover what the reference model uses
  * (cfg/default.yaml:48,50: D_MAX 8, K 7; correlation_tracker.py:26: stride 1): correlation d_max = 8, stride 1, W >= 20;
- * pooling k = 7; float32.  Everything else -- and all of float64 -- runs type-generic kernels (one thread per output
- * element, reference order): same results, measured on an MI355X (tools/envelope_cost.py, us forward / backward):
- *   correlation B=8 C=256 38x63   tuned 46 / 73     d_max=7: 668 / 6,743     stride 2: 787 / 2,539     f64: 1,230 / 11,216
+ * pooling k = 7; float32.  Everything else -- and all of float64 -- runs type-generic kernels in the reference's order (the
+ * correlation: d2t_corr_blocked.hip, four cells per thread forward, gradOut staged in LDS backward, bit-identical to the
+ * thread-per-element kernels D2T_IMPL_GENERIC selects; pooling: one thread per output element): same results, measured on an
+ * MI355X (tools/envelope_cost.py, us forward / backward):
+ *   correlation B=8 C=256 38x63   tuned 46 / 74     d_max=7: 546 / 1,351     stride 2: 571 / 1,083     f64: 1,230 / 2,072
+ *                                 (thread-per-element kernels, D2T_IMPL_GENERIC: 668 / 6,743, 787 / 2,539, 1,230 / 11,216)
  *   ROIPool R=300 C=1024 38x63    tuned 31 / 72     k=6: 168 / 2,346         f64: 270 / 3,105
  *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 510            f64: 25 / 640
  * (the Python wrappers warn once when a float32 call leaves the envelope under D2T_IMPL_AUTO).

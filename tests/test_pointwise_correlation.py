@@ -333,6 +333,29 @@ def test_strip_backward_kernels_nonfinite(impl):
         torch.testing.assert_close(got[fin], want[fin], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case", [(2, 5, 12, 21, 7, 1), (1, 70, 38, 63, 7, 1), (2, 9, 11, 13, 3, 2), (1, 33, 20, 40, 8, 2), (1, 3, 9, 4, 2, 1),
+                                  (1, 4, 7, 9, 0, 1), (2, 6, 15, 17, 5, 3), (1, 130, 19, 30, 12, 1), (1, 8, 6, 100, 9, 4)], ids=str)
+def test_outside_the_envelope_default_dispatch_equals_generic_kernels(case, dtype):
+    """Outside the tuned envelope (d_max != 8, stride > 1, narrow maps; all of f64) the default dispatch takes the blocked
+    kernels of d2t_corr_blocked.hip: the same arithmetic in the same order as the thread-per-element kernels
+    (pointwise_correlation_cuda.cu:105-107, 154-171), so forward AND both gradients are bit-identical to D2T_IMPL_GENERIC --
+    which test_matches_oracle pins to the oracle."""
+    from detect_to_track.models import _ext
+    B, C, H, W, d, s = case
+    g = torch.Generator().manual_seed(B * 100 + C)
+    fm0 = (torch.rand(B, C, H, W, generator=g, dtype=torch.float64) - 0.3).to(dtype).to(DEV)
+    fm1 = (torch.rand(B, C, H, W, generator=g, dtype=torch.float64) - 0.3).to(dtype).to(DEV)
+    gout = torch.randn(B, H, W, 2 * d + 1, 2 * d + 1, generator=g, dtype=torch.float64).to(dtype).to(DEV)
+    gout[0, 0, 0, 2 * d, 2 * d] = float("nan")                        # a cell the reference never visits: must not matter
+    a, b = _ext.pointwise_correlation_forward(fm0, fm1, d, s, 0), _ext.pointwise_correlation_forward(fm0, fm1, d, s, 1)
+    assert torch.equal(a, b)
+    a0, a1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, d, s, 0)
+    b0, b1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, d, s, 1)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    assert bool(torch.isfinite(a0).all()) and bool(torch.isfinite(a1).all())
+
+
 def test_north_star_shape_properties():
     """B=8 C=256 38x63 d=8 (BASELINE.json metric shape): size-independent properties."""
     from detect_to_track.models import _ext
