@@ -79,6 +79,129 @@ k_corr_fwd_blocked(const T* __restrict__ fm0, const T* __restrict__ fm1, T* __re
     }
 }
 
+
+// Forward, f32, LDS-tiled: workgroup = (b, tile of 4 x 8 pixels).  Per chunk of KC channels the tile's FM0 pixels and the FM1
+// window (4 + 2d rows x 8 + 2d columns, zero outside the map) are staged in LDS -- the NEXT chunk is already on its way into
+// registers while the current one is consumed.  Thread (pixel column pj, WINDOW row wrow) owns, for the four pixels (pi, pj) of
+// its column, the cell row ci = wrow - pi -- the four pixels read the SAME window row -- and walks the channels in ascending
+// order: one 16-byte LDS read of FM0[c][0..3][pj] and, per window column quad (16-byte aligned in the image whatever the pixel's
+// column: the left half of the tile reads quads 0 .. NG-1, the right half 1 .. NG, and quad g holds the cells cj = 4g + x - (pj & 3)),
+// one 16-byte LDS read for SIXTEEN fused multiply-adds.  Every cell is still one ascending-channel fma chain
+// (pointwise_correlation_cuda.cu:105-107): bit-identical to the thread-per-cell kernel.  Chains of cells that do not exist (ci or
+// cj outside the window, cells the reference's loops do not visit) are computed and discarded.
+// NG = ceil((4 + 2d) / 4): column quads per thread, the compile-time bound of the accumulator array; KC channels per chunk.
+constexpr int kTileH = 4, kTileW = 8;
+#ifndef TILED_ABL
+#define TILED_ABL 0                                                  // lab: 1 no multiply-adds, 2 no staging loads
+#endif
+
+template <int NG, int KC>
+__global__ void __launch_bounds__(kBlk)
+k_corr_fwd_tiled(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
+                 int B, int C, int H, int W, int d, int s)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int wcp = 4 * (NG + 1);                                 // window columns 8 + 2d, padded to whole quads (zeros)
+    constexpr int NPOS = (4 * NG * wcp + kBlk - 1) / kBlk;            // window elements per thread and channel (window rows <= 4 NG)
+    constexpr int NP0 = KC * kTileH * kTileW / kBlk;                  // tile pixels per thread and chunk (1 or 2)
+    const int cw = 2 * d + 1, plane = H * W;
+    const int wr = kTileH + 2 * d;                                    // window rows (<= 4 NG <= 32)
+    const int wimg = wr * wcp, cstride = wimg + kTileH * kTileW;      // floats per staged channel: window + the tile's pixels [pj][pi]
+    float* img = reinterpret_cast<float*>(lds_raw);
+    const int tiles_j = (W + kTileW - 1) / kTileW, tiles_i = (H + kTileH - 1) / kTileH;
+    int t = blockIdx.x;
+    const int tj = t % tiles_j; t /= tiles_j;
+    const int ti = t % tiles_i, b = t / tiles_i;
+    const int i0 = kTileH * ti, j0 = kTileW * tj;
+    const int tid = threadIdx.x, pj = tid & 7, wrow = tid >> 3;
+    const bool active = wrow < wr;
+    const float* f0b = fm0 + (size_t)b * C * plane;
+    const float* f1b = fm1 + (size_t)b * C * plane;
+
+    // what this thread stages: NPOS window positions (every channel of the chunk) and NP0 (channel, tile pixel) pairs
+    int src_off[NPOS], dst_off[NPOS];                                 // src < 0: outside the map (zero) or no such position
+#pragma unroll
+    for (int n = 0; n < NPOS; ++n) {
+        const int pos = tid + n * kBlk, row = pos / wcp, col = pos - row * wcp;
+        const int gi = i0 - d + row, gj = j0 - d + col;
+        dst_off[n] = pos < wimg ? pos : -1;
+        src_off[n] = (pos < wimg && gi >= 0 && gi < H && gj >= 0 && gj < W) ? gi * W + gj : -1;
+    }
+    const int q0 = tid & 31, q0i = q0 >> 3, q0j = q0 & 7;
+    const int src0 = (i0 + q0i < H && j0 + q0j < W) ? (i0 + q0i) * W + j0 + q0j : -1;
+    const int dst0 = wimg + q0j * kTileH + q0i, k0 = tid >> 5;        // channels k0, k0 + 8 of the chunk
+
+    float pre[NPOS][KC], pre0[NP0];
+    auto fetch = [&](int c0) {                                        // chunk c0 .. c0 + KC - 1 into registers (zeros past C)
+#pragma unroll
+        for (int n = 0; n < NPOS; ++n)
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                pre[n][k] = (src_off[n] >= 0 && c0 + k < C && !(TILED_ABL & 2)) ? f1b[(size_t)(c0 + k) * plane + src_off[n]] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NP0; ++n)
+            pre0[n] = (src0 >= 0 && c0 + k0 + 8 * n < C) ? f0b[(size_t)(c0 + k0 + 8 * n) * plane + src0] : 0.f;
+    };
+    f4 acc[kTileH][NG];
+#pragma unroll
+    for (int r = 0; r < kTileH; ++r)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[r][g] = f4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    for (int c0 = 0; c0 < C; c0 += KC) {
+        const int kc = C - c0 < KC ? C - c0 : KC;
+        __syncthreads();                                              // previous chunk consumed
+#pragma unroll
+        for (int n = 0; n < NPOS; ++n)
+            if (dst_off[n] >= 0) {
+#pragma unroll
+                for (int k = 0; k < KC; ++k) img[k * cstride + dst_off[n]] = pre[n][k];
+            }
+#pragma unroll
+        for (int n = 0; n < NP0; ++n) img[(k0 + 8 * n) * cstride + dst0] = pre0[n];
+        __syncthreads();
+        if (c0 + KC < C) fetch(c0 + KC);                              // in flight while this chunk is consumed
+        if (active && !(TILED_ABL & 1)) {
+            const float* ch = img;
+#pragma unroll 2
+            for (int k = 0; k < kc; ++k, ch += cstride) {             // ascending c
+                const f4 a = *reinterpret_cast<const f4*>(ch + wimg + pj * kTileH);
+                const f4* rowq = reinterpret_cast<const f4*>(ch + wrow * wcp) + (pj >> 2);
+                f4 q[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) q[g] = rowq[g];
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < kTileH; ++r)
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) acc[r][g][x] = fma_t(a[r], q[g][x], acc[r][g][x]);
+            }
+        }
+    }
+    const int j = j0 + pj;
+    if (!active || j >= W) return;
+#pragma unroll
+    for (int r = 0; r < kTileH; ++r) {
+        const int i = i0 + r, ci = wrow - r;                          // window row wrow is cell row wrow - r of pixel row r
+        if (i < H && ci >= 0 && ci < cw) {
+            float* o = out + ((size_t)(b * plane + i * W + j)) * cw * cw + ci * cw;
+            const bool row_hit = corr_axis_hit(i, i - d + ci, H, d, s);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int cj = 4 * g + x - (pj & 3);              // the cell this window column is for this pixel column
+                    if (cj >= 0 && cj < cw)
+                        o[cj] = row_hit && corr_axis_hit(j, j - d + cj, W, d, s) ? acc[r][g][x] : 0.f;   // structural zeros included
+                }
+            }
+        }
+    }
+}
+
 // gradOut re-indexed by the displaced pixel: goutT[b][y][x][ci][cj] = gradOut[b][y - ci + d][x - cj + d][ci][cj] where that centre
 // exists (elsewhere the value is never read: the consumer applies the same test).
 template <typename T>
@@ -148,6 +271,105 @@ k_corr_bwd_blocked(const T* __restrict__ G, const T* __restrict__ S, T* __restri
     }
 }
 
+
+// One gradient, f32, register-tiled (d <= 14).  Same sums in the same order as k_corr_bwd_blocked -- thread-owned, rows then columns
+// ascending -- but a thread owns FOUR adjacent pixels of the row and CT channels: per window row it loads, per channel, the
+// 4 NQ >= 2d + 4 values of S its four windows span with 16-byte loads, and every gradOut cell it reads from LDS feeds CT fused
+// multiply-adds.  (k_corr_bwd_blocked issues one LDS read and one 4-byte global load per multiply-add.)  Which columns k of the
+// window exist for pixel px (map edge, stride, the never-visited last column) does not depend on the row or the channel: one bit
+// mask per pixel, and a term whose bit is clear is not executed at all -- non-finite values outside the window cannot leak in.
+template <bool MIRROR, int NQ, int CT>
+__global__ void __launch_bounds__(kBlk)
+k_corr_bwd_tiled(const float* __restrict__ G, const float* __restrict__ S, float* __restrict__ gx,
+                 int B, int C, int H, int W, int d, int s, int XT, int CB)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    typedef Vec4<float>::type V4;
+    float* gl = reinterpret_cast<float*>(lds_raw);                    // [XT][cells]
+    const int cw = 2 * d + 1, cells = cw * cw, plane = H * W;
+    const int xtiles = (W + XT - 1) / XT, cblocks = (C + CB - 1) / CB;
+    int t = blockIdx.x;
+    const int cb = t % cblocks; t /= cblocks;
+    const int xt = t % xtiles; t /= xtiles;
+    const int y = t % H, b = t / H;
+    const int xb = xt * XT, nx = W - xb < XT ? W - xb : XT;
+    const float* gsrc = G + ((size_t)(b * plane + y * W + xb)) * cells;   // nx * cells contiguous elements
+    for (int e = threadIdx.x; e < nx * cells; e += kBlk) gl[e] = gsrc[e];
+    __syncthreads();
+    const int nxg = XT >> 2, xg = threadIdx.x % nxg, cl = threadIdx.x / nxg, nch = kBlk / nxg;
+    const int x0 = xb + 4 * xg;
+    if (4 * xg >= nx) return;
+    unsigned mask[4];                                                 // bit k: column x - d + k belongs to the sum of pixel x = x0 + px
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+        const int x = x0 + px;
+        unsigned m = 0;
+        if (x < W) {
+            const int lo_j = x - d > 0 ? x - d : 0, hi_j = x + d < W ? x + d : W;
+            for (int k = 0; k < cw; ++k) {
+                const int col = x - d + k;
+                const bool ok = MIRROR ? (col >= 0 && col < W && corr_axis_hit(col, x, W, d, s))
+                                       : (col >= lo_j && col < hi_j && (col - lo_j) % s == 0);
+                m |= ok ? 1u << k : 0u;
+            }
+        }
+        mask[px] = m;
+    }
+    const float* glx = gl + (size_t)(4 * xg) * cells;
+    const int c_end = (cb + 1) * CB < C ? (cb + 1) * CB : C;
+    // rows of the sum (the same for every pixel of the row y): first, last, step; MIRROR tests each row
+    const int r_lo = y - d > 0 ? y - d : 0;
+    const int r_hi = MIRROR ? (y + d < H - 1 ? y + d : H - 1) : (y + d < H ? y + d : H) - 1;
+    const int r_step = MIRROR ? 1 : s;
+    for (int c0 = cb * CB + cl * CT; c0 < c_end; c0 += nch * CT) {
+        float acc[CT][4];
+#pragma unroll
+        for (int ch = 0; ch < CT; ++ch)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) acc[ch][px] = 0.f;
+        for (int row = r_lo; row <= r_hi; row += r_step) {
+            if (MIRROR && !corr_axis_hit(row, y, H, d, s)) continue;
+            const int rc = MIRROR ? y - row + d : row - y + d;        // cell row
+            float seg[CT][4 * NQ];
+#pragma unroll
+            for (int ch = 0; ch < CT; ++ch) {
+                const int cc = c0 + ch < C ? c0 + ch : C - 1;
+                const float* sp = S + ((size_t)b * C + cc) * plane + row * W;
+#pragma unroll
+                for (int m = 0; m < NQ; ++m) {
+                    const int col = x0 - d + 4 * m;
+                    if (col >= 0 && col + 3 < W) {
+                        const V4 v = *reinterpret_cast<const V4*>(sp + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) seg[ch][4 * m + e] = v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) seg[ch][4 * m + e] = (col + e >= 0 && col + e < W) ? sp[col + e] : 0.f;
+                    }
+                }
+            }
+            const float* gr = glx + rc * cw + (MIRROR ? 2 * d : 0);   // cell (rc, k) -- MIRROR: (rc, 2d - k)
+#pragma unroll
+            for (int k = 0; k < 4 * NQ - 3; ++k)                      // columns ascending
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+                    if ((mask[px] >> k) & 1u) {
+                        const float gv = gr[px * cells + (MIRROR ? -k : k)];
+#pragma unroll
+                        for (int ch = 0; ch < CT; ++ch) acc[ch][px] = fma_t(gv, seg[ch][k + px], acc[ch][px]);
+                    }
+        }
+#pragma unroll
+        for (int ch = 0; ch < CT; ++ch)
+            if (c0 + ch < c_end) {
+                float* o = gx + ((size_t)b * C + c0 + ch) * plane + y * W + x0;
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+                    if (x0 + px < W) o[px] = acc[ch][px];
+            }
+    }
+}
+
 // pixels of a row per workgroup: a power of two <= 64 whose cells fit 48 KB of LDS (0: the window is too large for this form)
 template <typename T>
 int blocked_xt(int W, int d)
@@ -177,13 +399,62 @@ size_t corr_bwd_blocked_ws_bytes(int B, int C, int H, int W, int d, int s)
     return ((size_t)B * H * W * cw * cw * sizeof(T) + 255) / 256 * 256;   // gradOut by displaced pixel
 }
 
+constexpr int kTiledMaxD = (kBlk / kTileW - kTileH) / 2;              // window rows <= threads / 8: d <= 14
+
+static int corr_fwd_tiled_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int s, hipStream_t st)
+{
+    const int ng = (kTileH + 2 * d + 3) / 4 < 2 ? 2 : (kTileH + 2 * d + 3) / 4;        // column quads per thread: 2 .. 8
+    const int wr = kTileH + 2 * d, wcp = 4 * (ng + 1), cstride = wr * wcp + kTileH * kTileW;
+    const int grid = B * ((H + kTileH - 1) / kTileH) * ((W + kTileW - 1) / kTileW);
+    switch (ng) {
+#define D2T_TILED(N, K) case N: hipLaunchKernelGGL((k_corr_fwd_tiled<N, K>), dim3(grid), dim3(kBlk), (size_t)K * cstride * sizeof(float), st, \
+                                                   fm0, fm1, out, B, C, H, W, d, s); break;
+        D2T_TILED(2, 16) D2T_TILED(3, 16) D2T_TILED(4, 16) D2T_TILED(5, 16) D2T_TILED(6, 8) D2T_TILED(7, 8) D2T_TILED(8, 8)
+#undef D2T_TILED
+        default: return D2T_EINVAL;
+    }
+    return launch_status();
+}
+
 template <typename T>
 int corr_fwd_blocked(const T* fm0, const T* fm1, T* out, int B, int C, int H, int W, int d, int s, hipStream_t st)
 {
     const long long cw = 2LL * d + 1, total = 1LL * B * H * W * cw * ((cw + 3) / 4);
     if (total == 0) return D2T_OK;
+    if (sizeof(T) == 4 && d <= kTiledMaxD && 1LL * B * ((H + 3) / 4) * ((W + 7) / 8) < 0x7fffffffLL)       // LDS-tiled form (f32)
+        return corr_fwd_tiled_f32(reinterpret_cast<const float*>(fm0), reinterpret_cast<const float*>(fm1), reinterpret_cast<float*>(out), B, C, H, W, d, s, st);
     hipLaunchKernelGGL(k_corr_fwd_blocked<T>, dim3(grid_for(total, kBlk, 256 * 32)), dim3(kBlk), 0, st, fm0, fm1, out, B, C, H, W, d, s);
     return launch_status();
+}
+
+static int corr_bwd_tiled_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1, int B, int C, int H, int W,
+                              int d, int s, int XT, float* goutT, hipStream_t st)
+{
+    constexpr int CT = 4;
+    const long long cw = 2LL * d + 1, cells = cw * cw;
+    const int nq = (int)(cw + 3 + 3) / 4;                             // 16-byte pieces spanning the four windows of a thread: 1 .. 8
+    const int CB = (kBlk / (XT / 4)) * CT < 64 ? 64 : (kBlk / (XT / 4)) * CT;   // one channel pass per workgroup where C allows
+    const size_t lds = (size_t)XT * cells * sizeof(float);
+    const int grid = B * H * ((W + XT - 1) / XT) * ((C + CB - 1) / CB);
+    int rc = D2T_OK;
+    for (int pass = 0; pass < 2 && rc == D2T_OK; ++pass) {
+        const float* G = pass ? goutT : gout;
+        const float* S = pass ? fm0 : fm1;
+        float* gx = pass ? g1 : g0;
+        if (pass) {
+            hipLaunchKernelGGL(k_corr_gout_by_displaced<float>, dim3(grid_for(1LL * B * H * W * cells, kBlk, 256 * 32)), dim3(kBlk), 0, st, gout, goutT, B, H, W, d);
+            if ((rc = launch_status()) != D2T_OK) break;
+        }
+        switch (nq) {
+#define D2T_TILED(N) case N: if (pass) hipLaunchKernelGGL((k_corr_bwd_tiled<true, N, CT>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, d, s, XT, CB); \
+                             else hipLaunchKernelGGL((k_corr_bwd_tiled<false, N, CT>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, d, s, XT, CB); break;
+            D2T_TILED(1) D2T_TILED(2) D2T_TILED(3) D2T_TILED(4) D2T_TILED(5) D2T_TILED(6) D2T_TILED(7) D2T_TILED(8)
+#undef D2T_TILED
+            default: return D2T_EINVAL;
+        }
+        rc = launch_status();
+    }
+    return rc;
 }
 
 template <typename T>
@@ -196,6 +467,9 @@ int corr_bwd_blocked(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1, in
     const size_t lds = (size_t)XT * cells * sizeof(T);
     const int grid = B * H * ((W + XT - 1) / XT) * ((C + CB - 1) / CB);
     T* goutT = static_cast<T*>(ws);
+    if (sizeof(T) == 4 && d <= kTiledMaxD && XT >= 4)                 // register-tiled form (f32)
+        return corr_bwd_tiled_f32(reinterpret_cast<const float*>(gout), reinterpret_cast<const float*>(fm0), reinterpret_cast<const float*>(fm1),
+                                  reinterpret_cast<float*>(g0), reinterpret_cast<float*>(g1), B, C, H, W, d, s, XT, reinterpret_cast<float*>(goutT), st);
     hipLaunchKernelGGL((k_corr_bwd_blocked<T, false>), dim3(grid), dim3(kBlk), lds, st, gout, fm1, g0, B, C, H, W, d, s, XT, CB);
     int rc = launch_status();
     if (rc != D2T_OK) return rc;

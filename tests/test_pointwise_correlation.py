@@ -335,7 +335,8 @@ def test_strip_backward_kernels_nonfinite(impl):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("case", [(2, 5, 12, 21, 7, 1), (1, 70, 38, 63, 7, 1), (2, 9, 11, 13, 3, 2), (1, 33, 20, 40, 8, 2), (1, 3, 9, 4, 2, 1),
-                                  (1, 4, 7, 9, 0, 1), (2, 6, 15, 17, 5, 3), (1, 130, 19, 30, 12, 1), (1, 8, 6, 100, 9, 4)], ids=str)
+                                  (1, 4, 7, 9, 0, 1), (2, 6, 15, 17, 5, 3), (1, 130, 19, 30, 12, 1), (1, 8, 6, 100, 9, 4),
+                                  (1, 21, 9, 11, 16, 1), (1, 5, 6, 7, 20, 1), (2, 17, 5, 6, 1, 1), (1, 40, 13, 22, 10, 2), (1, 19, 3, 2, 4, 1)], ids=str)
 def test_outside_the_envelope_default_dispatch_equals_generic_kernels(case, dtype):
     """Outside the tuned envelope (d_max != 8, stride > 1, narrow maps; all of f64) the default dispatch takes the blocked
     kernels of d2t_corr_blocked.hip: the same arithmetic in the same order as the thread-per-element kernels
