@@ -272,19 +272,32 @@ k_corr_bwd_blocked(const T* __restrict__ G, const T* __restrict__ S, T* __restri
 }
 
 
+// A feature map with d zero columns before and >= d + 6 after every row (row pitch Wp, a multiple of 4): what the register-tiled
+// backward reads its 16-byte pieces from -- every piece is aligned and inside the row, no edge cases.
+__global__ void __launch_bounds__(kBlk)
+k_corr_pad_rows(const float* __restrict__ S, float* __restrict__ P, long long rows, int W, int Wp, int d)
+{
+    const long long total = rows * Wp;
+    for (long long i64 = (long long)blockIdx.x * kBlk + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlk) {
+        const long long row = i64 / Wp;
+        const int col = (int)(i64 - row * Wp) - d;
+        P[i64] = (col >= 0 && col < W) ? S[row * W + col] : 0.f;
+    }
+}
+
 // One gradient, f32, register-tiled (d <= 14).  Same sums in the same order as k_corr_bwd_blocked -- thread-owned, rows then columns
 // ascending -- but a thread owns FOUR adjacent pixels of the row and CT channels: per window row it loads, per channel, the
-// 4 NQ >= 2d + 4 values of S its four windows span with 16-byte loads, and every gradOut cell it reads from LDS feeds CT fused
+// 4 NQ >= 2d + 4 values of S its four windows span with aligned 16-byte loads (S comes with zero-padded rows, k_corr_pad_rows), and every gradOut cell it reads from LDS feeds CT fused
 // multiply-adds.  (k_corr_bwd_blocked issues one LDS read and one 4-byte global load per multiply-add.)  Which columns k of the
 // window exist for pixel px (map edge, stride, the never-visited last column) does not depend on the row or the channel: one bit
 // mask per pixel, and a term whose bit is clear is not executed at all -- non-finite values outside the window cannot leak in.
 template <bool MIRROR, int NQ, int CT>
 __global__ void __launch_bounds__(kBlk)
 k_corr_bwd_tiled(const float* __restrict__ G, const float* __restrict__ S, float* __restrict__ gx,
-                 int B, int C, int H, int W, int d, int s, int XT, int CB)
+                 int B, int C, int H, int W, int Wp, int d, int s, int XT, int CB)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    typedef Vec4<float>::type V4;
+    typedef float f4v __attribute__((ext_vector_type(4)));
     float* gl = reinterpret_cast<float*>(lds_raw);                    // [XT][cells]
     const int cw = 2 * d + 1, cells = cw * cw, plane = H * W;
     const int xtiles = (W + XT - 1) / XT, cblocks = (C + CB - 1) / CB;
@@ -334,18 +347,12 @@ k_corr_bwd_tiled(const float* __restrict__ G, const float* __restrict__ S, float
 #pragma unroll
             for (int ch = 0; ch < CT; ++ch) {
                 const int cc = c0 + ch < C ? c0 + ch : C - 1;
-                const float* sp = S + ((size_t)b * C + cc) * plane + row * W;
+                const f4v* sp = reinterpret_cast<const f4v*>(S + (((size_t)b * C + cc) * H + row) * Wp + x0);   // padded column x0 = column x0 - d
 #pragma unroll
                 for (int m = 0; m < NQ; ++m) {
-                    const int col = x0 - d + 4 * m;
-                    if (col >= 0 && col + 3 < W) {
-                        const V4 v = *reinterpret_cast<const V4*>(sp + col);
+                    const f4v v = sp[m];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) seg[ch][4 * m + e] = v[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) seg[ch][4 * m + e] = (col + e >= 0 && col + e < W) ? sp[col + e] : 0.f;
-                    }
+                    for (int e = 0; e < 4; ++e) seg[ch][4 * m + e] = v[e];
                 }
             }
             const float* gr = glx + rc * cw + (MIRROR ? 2 * d : 0);   // cell (rc, k) -- MIRROR: (rc, 2d - k)
@@ -391,15 +398,19 @@ bool corr_blocked_supported(int B, int C, int H, int W, int d, int s)
     return fits_i32(1LL * B * H * W * cw * cw) && fits_i32(1LL * B * C * H * W) && 1LL * B * H * 64 * ((C + 63) / 64) < 0x7fffffffLL;
 }
 
+constexpr int kTiledMaxD = (kBlk / kTileW - kTileH) / 2;              // window rows <= threads / 8: d <= 14
+static int tiled_pitch(int W, int d) { return (W + 2 * d + 6 + 3) & ~3; }   // row pitch of the zero-padded maps
+
 template <typename T>
 size_t corr_bwd_blocked_ws_bytes(int B, int C, int H, int W, int d, int s)
 {
     if (!corr_blocked_supported<T>(B, C, H, W, d, s)) return 0;
     const size_t cw = 2 * (size_t)d + 1;
-    return ((size_t)B * H * W * cw * cw * sizeof(T) + 255) / 256 * 256;   // gradOut by displaced pixel
+    size_t bytes = ((size_t)B * H * W * cw * cw * sizeof(T) + 255) / 256 * 256;   // gradOut by displaced pixel
+    if (sizeof(T) == 4 && d <= kTiledMaxD) bytes += 2 * (size_t)B * C * H * tiled_pitch(W, d) * sizeof(float);   // + both maps with padded rows
+    return bytes;
 }
 
-constexpr int kTiledMaxD = (kBlk / kTileW - kTileH) / 2;              // window rows <= threads / 8: d <= 14
 
 static int corr_fwd_tiled_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int s, hipStream_t st)
 {
@@ -432,6 +443,12 @@ static int corr_bwd_tiled_f32(const float* gout, const float* fm0, const float* 
 {
     constexpr int CT = 4;
     const long long cw = 2LL * d + 1, cells = cw * cw;
+    const int Wp = tiled_pitch(W, d);
+    const long long rows = 1LL * B * C * H;
+    float* pad0 = goutT + ((size_t)B * H * W * cells + 63) / 64 * 64;     // workspace: gradOut by displaced pixel | FM0 padded | FM1 padded
+    float* pad1 = pad0 + (size_t)rows * Wp;
+    hipLaunchKernelGGL(k_corr_pad_rows, dim3(grid_for(rows * Wp, kBlk, 256 * 32)), dim3(kBlk), 0, st, fm0, pad0, rows, W, Wp, d);
+    hipLaunchKernelGGL(k_corr_pad_rows, dim3(grid_for(rows * Wp, kBlk, 256 * 32)), dim3(kBlk), 0, st, fm1, pad1, rows, W, Wp, d);
     const int nq = (int)(cw + 3 + 3) / 4;                             // 16-byte pieces spanning the four windows of a thread: 1 .. 8
     const int CB = (kBlk / (XT / 4)) * CT < 64 ? 64 : (kBlk / (XT / 4)) * CT;   // one channel pass per workgroup where C allows
     const size_t lds = (size_t)XT * cells * sizeof(float);
@@ -439,15 +456,15 @@ static int corr_bwd_tiled_f32(const float* gout, const float* fm0, const float* 
     int rc = D2T_OK;
     for (int pass = 0; pass < 2 && rc == D2T_OK; ++pass) {
         const float* G = pass ? goutT : gout;
-        const float* S = pass ? fm0 : fm1;
+        const float* S = pass ? pad0 : pad1;
         float* gx = pass ? g1 : g0;
         if (pass) {
             hipLaunchKernelGGL(k_corr_gout_by_displaced<float>, dim3(grid_for(1LL * B * H * W * cells, kBlk, 256 * 32)), dim3(kBlk), 0, st, gout, goutT, B, H, W, d);
             if ((rc = launch_status()) != D2T_OK) break;
         }
         switch (nq) {
-#define D2T_TILED(N) case N: if (pass) hipLaunchKernelGGL((k_corr_bwd_tiled<true, N, CT>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, d, s, XT, CB); \
-                             else hipLaunchKernelGGL((k_corr_bwd_tiled<false, N, CT>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, d, s, XT, CB); break;
+#define D2T_TILED(N) case N: if (pass) hipLaunchKernelGGL((k_corr_bwd_tiled<true, N, CT>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, Wp, d, s, XT, CB); \
+                             else hipLaunchKernelGGL((k_corr_bwd_tiled<false, N, CT>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, Wp, d, s, XT, CB); break;
             D2T_TILED(1) D2T_TILED(2) D2T_TILED(3) D2T_TILED(4) D2T_TILED(5) D2T_TILED(6) D2T_TILED(7) D2T_TILED(8)
 #undef D2T_TILED
             default: return D2T_EINVAL;
