@@ -229,7 +229,11 @@ size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int el
 {
     const size_t generic = bins_bytes(R, k);
     const size_t t = elem_size == 4 ? tuned::roipool_bwd_ws_bytes(R, C, H, W, k) : 0;
-    return generic > t ? generic : t;
+    size_t lists = 0;                                                 // outside the tuned envelope: d2t_pool_lists.hip
+    if (elem_size == 4 && !tuned::roipool_bwd_supported(R, C, H, W, k)) lists = roipool_bwd_lists_ws_bytes<float>(R, C, H, W, k);
+    if (elem_size == 8) lists = roipool_bwd_lists_ws_bytes<double>(R, C, H, W, k);
+    const size_t m = generic > t ? generic : t;
+    return m > lists ? m : lists;
 }
 
 int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int k,
@@ -269,6 +273,8 @@ int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R,
         return tuned::roipool_bwd_f32(gout, rois, gin, R, C, H, W, k, ws, as_stream(stream));
     }
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
+    if (impl != D2T_IMPL_GENERIC && roipool_bwd_lists_supported<float>(R, C, H, W, k) && ws_bytes >= roipool_bwd_lists_ws_bytes<float>(R, C, H, W, k))
+        return roipool_bwd_lists<float>(gout, rois, gin, ws, R, C, H, W, k, as_stream(stream));
     return roipool_bwd_generic<float>(gout, rois, gin, static_cast<int32_t*>(ws), R, C, H, W, k, as_stream(stream));
 }
 
@@ -279,6 +285,8 @@ int d2t_roipool_bwd_f64(const double* gout, const double* rois, double* gin, int
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
+    if (impl != D2T_IMPL_GENERIC && roipool_bwd_lists_supported<double>(R, C, H, W, k) && ws_bytes >= roipool_bwd_lists_ws_bytes<double>(R, C, H, W, k))
+        return roipool_bwd_lists<double>(gout, rois, gin, ws, R, C, H, W, k, as_stream(stream));
     return roipool_bwd_generic<double>(gout, rois, gin, static_cast<int32_t*>(ws), R, C, H, W, k, as_stream(stream));
 }
 

@@ -38,6 +38,14 @@ template <typename T> int    corr_fwd_blocked(const T* fm0, const T* fm1, T* out
 template <typename T> int    corr_bwd_blocked(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1,
                                               int B, int C, int H, int W, int d, int s, void* ws, hipStream_t st);
 
+// ---- ROIPool backward outside the tuned envelope (d2t_pool_lists.hip): per-pixel bin lists built once, shared by all channels;
+// bit-identical to roipool_bwd_generic.  ws: bins | list offsets | list entries | gradOut / n by (bin, channel)
+template <typename T> bool   roipool_bwd_lists_supported(int R, int C, int H, int W, int k);
+template <typename T> size_t roipool_bwd_lists_ws_bytes(int R, int C, int H, int W, int k);
+template <typename T> int    roipool_bwd_lists(const T* gout, const T* rois, T* gin, void* ws, int R, int C, int H, int W, int k, hipStream_t st);
+template <typename T> int    roipool_bwd_generic_gated(const T* gout, const int32_t* bins, T* gin, const int32_t* gate, int cap,
+                                                       int R, int C, int H, int W, int k, hipStream_t st);
+
 // ---- region proposals on the device (d2t_regions.hip): decode + confidence filter + top-k + greedy NMS
 size_t region_filter_ws_bytes(int A, int max_dets);
 int region_max_dets();

@@ -357,6 +357,36 @@ def test_outside_the_envelope_default_dispatch_equals_generic_kernels(case, dtyp
     assert bool(torch.isfinite(a0).all()) and bool(torch.isfinite(a1).all())
 
 
+def test_outside_the_envelope_random_shapes_equal_generic_kernels():
+    """Seeded random shapes around every boundary of the tiled / blocked kernels of d2t_corr_blocked.hip (d_max 0..17: the tiled forms
+    stop at 14; stride 1..4; maps narrower than a tile, channel counts that are not multiples of the channel chunk; non-finite values
+    in cells and positions the reference never reads): forward and both gradients equal D2T_IMPL_GENERIC bit for bit."""
+    from detect_to_track.models import _ext
+    rng = np.random.default_rng(2024)
+    for n in range(60):
+        d = int(rng.integers(0, 18))
+        s = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        if d == 8 and s == 1:                                         # (the tuned envelope: its gradients are not bit-equal to the generic kernels)
+            d = 9
+        B, C = int(rng.integers(1, 3)), int(rng.choice([1, 3, 7, 16, 17, 33, 64, 130]))
+        H, W = int(rng.integers(1, 24)), int(rng.integers(4, 45))
+        if (2 * d + 1) ** 2 * B * H * W > 3_000_000:
+            H = max(1, 3_000_000 // ((2 * d + 1) ** 2 * B * W))
+        g = torch.Generator().manual_seed(n)
+        fm0 = (torch.rand(B, C, H, W, generator=g) - 0.4).to(DEV)
+        fm1 = (torch.rand(B, C, H, W, generator=g) - 0.4).to(DEV)
+        gout = torch.randn(B, H, W, 2 * d + 1, 2 * d + 1, generator=g).to(DEV)
+        gout[:, :, :, 2 * d, :] = float("nan")                        # cell row / column 2d: never visited (:88-93)
+        gout[:, :, :, :, 2 * d] = float("inf")
+        tag = f"case {n}: B={B} C={C} H={H} W={W} d={d} s={s}"
+        a, b = _ext.pointwise_correlation_forward(fm0, fm1, d, s, 0), _ext.pointwise_correlation_forward(fm0, fm1, d, s, 1)
+        assert torch.equal(a, b), tag
+        a0, a1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, d, s, 0)
+        b0, b1 = _ext.pointwise_correlation_backward(gout, fm0, fm1, d, s, 1)
+        assert torch.equal(a0, b0) and torch.equal(a1, b1), tag
+        assert bool(torch.isfinite(a0).all()) and bool(torch.isfinite(a1).all()), tag
+
+
 def test_north_star_shape_properties():
     """B=8 C=256 38x63 d=8 (BASELINE.json metric shape): size-independent properties."""
     from detect_to_track.models import _ext

@@ -193,6 +193,37 @@ def test_nonfinite_gradout(case):
     torch.testing.assert_close(got[fin], want[fin], rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case", [(300, 130, 38, 63, 6, "random"), (40, 1030, 20, 31, 3, "random"), (17, 5, 9, 14, 14, "random"), (9, 3, 7, 5, 1, "random"),
+                                  (300, 64, 38, 63, 8, "adversarial"), (30, 7, 20, 30, 5, "negative"), (520, 9, 12, 17, 2, "random"),
+                                  (12, 6, 20, 20, 3, "huge")], ids=str)
+def test_outside_the_envelope_backward_equals_generic_kernel(case, dtype):
+    """Bin counts other than 7 (and all of f64) take the per-pixel bin lists of d2t_pool_lists.hip under the default dispatch: the same
+    terms gradOut / n in the same ascending (r, i, j) order as the thread-per-pixel kernel (roipool_cuda.cu:112-124, gather form), so
+    the gradient is bit-identical to D2T_IMPL_GENERIC, which test_matches_oracle pins to the oracle.  "huge": RoIs many times the
+    map, whose lists exceed the workspace -- the device-side fallback to the thread-per-pixel kernel.  Non-finite gradOut included."""
+    from detect_to_track.models import _ext
+    R, C, H, W, k, kind = case
+    rng = np.random.default_rng(R * 31 + k)
+    if kind == "random":
+        rois = random_rois(R, k)
+    elif kind == "adversarial":
+        rois = np.resize(ADVERSARIAL_ROIS, (R, 4))
+    elif kind == "negative":
+        rois = np.resize(NEGATIVE_ROIS, (R, 4))
+    else:
+        rois = np.concatenate([rng.random((R, 2)), 20 + 30 * rng.random((R, 2))], axis=1)
+    gout = rng.standard_normal((R, C, k, k))
+    gout[0, 0, 0, 0] = np.inf
+    gout[R - 1, C - 1, k - 1, k - 1] = np.nan
+    g, r = _t(gout.astype(dtype)), _t(np.asarray(rois).astype(dtype))
+    got = _ext.roipool_backward(g, r, H, W, 0)
+    want = _ext.roipool_backward(g, r, H, W, 1)
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    fin = ~torch.isnan(want)
+    assert torch.equal(got[fin], want[fin])
+
+
 def test_config3_properties():
     """R=300 C=1024 38x63 k=7 (BASELINE.json config 3): size-independent properties."""
     from detect_to_track.models import _ext
