@@ -299,7 +299,10 @@ size_t d2t_psroipool_bwd_workspace_bytes(int R, int nT, int H, int W, int k, int
 {
     const size_t generic = bins_bytes(R, k);
     const size_t t = elem_size == 4 ? tuned::psroipool_bwd_ws_bytes(R, nT, H, W, k) : 0;
-    return generic > t ? generic : t;
+    size_t lists = 0;                                                 // outside the tuned envelope: d2t_pool_lists.hip
+    if ((elem_size == 4 && !tuned::psroipool_bwd_supported(R, nT, H, W, k)) || elem_size == 8) lists = psroipool_bwd_lists_ws_bytes(R, nT, H, W, k);
+    const size_t m = generic > t ? generic : t;
+    return m > lists ? m : lists;
 }
 
 static int check_ps(const void* fm, const void* rois, const void* out, int R, int nT, int H, int W, int k)
@@ -346,6 +349,8 @@ int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int 
         return tuned::psroipool_bwd_f32(gout, rois, gin, R, nT, H, W, k, ws, as_stream(stream));
     }
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
+    if (impl != D2T_IMPL_GENERIC && psroipool_bwd_lists_supported(R, nT, H, W, k) && ws_bytes >= psroipool_bwd_lists_ws_bytes(R, nT, H, W, k))
+        return psroipool_bwd_lists<float>(gout, rois, gin, ws, R, nT, H, W, k, as_stream(stream));
     return psroipool_bwd_generic<float>(gout, rois, gin, static_cast<int32_t*>(ws), R, nT, H, W, k, as_stream(stream));
 }
 
@@ -356,6 +361,8 @@ int d2t_psroipool_bwd_f64(const double* gout, const double* rois, double* gin, i
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
+    if (impl != D2T_IMPL_GENERIC && psroipool_bwd_lists_supported(R, nT, H, W, k) && ws_bytes >= psroipool_bwd_lists_ws_bytes(R, nT, H, W, k))
+        return psroipool_bwd_lists<double>(gout, rois, gin, ws, R, nT, H, W, k, as_stream(stream));
     return psroipool_bwd_generic<double>(gout, rois, gin, static_cast<int32_t*>(ws), R, nT, H, W, k, as_stream(stream));
 }
 

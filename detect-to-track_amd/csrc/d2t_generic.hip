@@ -160,9 +160,9 @@ __global__ void k_roipool_bins(const T* __restrict__ rois, int32_t* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_roipool_bwd_generic(const T* __restrict__ gout, const int32_t* __restrict__ bins, T* __restrict__ gin,
-                      int R, int C, int H, int W, int k, const int32_t* __restrict__ gate = nullptr, int gate_cap = 0)
+                      int R, int C, int H, int W, int k, const unsigned long long* __restrict__ gate = nullptr, long long gate_cap = 0)
 {
-    if (gate && *gate <= gate_cap) return;                           // (d2t_pool_lists.hip: only when its lists overflowed)
+    if (gate && (long long)*gate <= gate_cap) return;                           // (d2t_pool_lists.hip: only when its lists overflowed)
     const int total = C * H * W;
     const int4* bt = reinterpret_cast<const int4*>(bins);
     for (long long i64 = (long long)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlock) {
@@ -238,8 +238,9 @@ __global__ void k_psroipool_channels(int32_t* __restrict__ ch, int nT, int k)
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_psroipool_bwd_generic(const T* __restrict__ gout, const int32_t* __restrict__ cells, T* __restrict__ gin,
-                        int R, int nT, int H, int W, int k)
+                        int R, int nT, int H, int W, int k, const unsigned long long* __restrict__ gate = nullptr, long long gate_cap = 0)
 {
+    if (gate && (long long)*gate <= gate_cap) return;                // (d2t_pool_lists.hip: only when its lists overflowed)
     const int kk = k * k;
     const int total = nT * kk * H * W;
     const int4* ct = reinterpret_cast<const int4*>(cells);
@@ -348,13 +349,24 @@ int roipool_bwd_generic(const T* gout, const T* rois, T* gin, int32_t* bins,
 
 // the same kernel behind a device-side gate: it runs only if *gate > cap (d2t_pool_lists.hip); `bins` already written
 template <typename T>
-int roipool_bwd_generic_gated(const T* gout, const int32_t* bins, T* gin, const int32_t* gate, int cap,
+int roipool_bwd_generic_gated(const T* gout, const int32_t* bins, T* gin, const unsigned long long* gate, long long cap,
                               int R, int C, int H, int W, int k, hipStream_t st)
 {
     const long long total = 1LL * C * H * W;
     if (total == 0) return D2T_OK;
     hipLaunchKernelGGL(k_roipool_bwd_generic<T>, dim3(grid_for(total, kBlock, 256 * 32)), dim3(kBlock), 0, st,
                        gout, bins, gin, R, C, H, W, k, gate, cap);
+    return launch_status();
+}
+
+template <typename T>
+int psroipool_bwd_generic_gated(const T* gout, const int32_t* cells, T* gin, const unsigned long long* gate, long long cap,
+                                int R, int nT, int H, int W, int k, hipStream_t st)
+{
+    const long long total = 1LL * nT * k * k * H * W;
+    if (total == 0) return D2T_OK;
+    hipLaunchKernelGGL(k_psroipool_bwd_generic<T>, dim3(grid_for(total, kBlock, 256 * 32)), dim3(kBlock), 0, st,
+                       gout, cells, gin, R, nT, H, W, k, gate, cap);
     return launch_status();
 }
 
@@ -394,7 +406,8 @@ int psroipool_bwd_generic(const T* gout, const T* rois, T* gin, int32_t* cells,
     template int corr_bwd_generic<T>(const T*, const T*, const T*, T*, T*, int, int, int, int, int, int, hipStream_t, int, int, long long); \
     template int roipool_fwd_generic<T>(const T*, const T*, T*, int, int, int, int, int, hipStream_t);   \
     template int roipool_bwd_generic<T>(const T*, const T*, T*, int32_t*, int, int, int, int, int, hipStream_t); \
-    template int roipool_bwd_generic_gated<T>(const T*, const int32_t*, T*, const int32_t*, int, int, int, int, int, int, hipStream_t); \
+    template int roipool_bwd_generic_gated<T>(const T*, const int32_t*, T*, const unsigned long long*, long long, int, int, int, int, int, hipStream_t); \
+    template int psroipool_bwd_generic_gated<T>(const T*, const int32_t*, T*, const unsigned long long*, long long, int, int, int, int, int, hipStream_t); \
     template int psroipool_fwd_generic<T>(const T*, const T*, T*, int, int, int, int, int, hipStream_t); \
     template int psroipool_bwd_generic<T>(const T*, const T*, T*, int32_t*, int, int, int, int, int, hipStream_t); \
     template int roipool_bins<T>(const T*, int32_t*, int, int, int, int, hipStream_t);                   \

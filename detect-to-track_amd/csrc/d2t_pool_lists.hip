@@ -4,18 +4,23 @@
 // Which bins contain a pixel does not depend on the channel; the thread-per-(c, y, x) kernel re-derives it per channel
 // (C x H x W x R bin tests: 2.3 ms at R = 300, C = 1024, 38 x 63).  Here:
 //
-//   1. k_cover_count / k_cover_scan / k_cover_fill   per pixel, the list of the bins (r, i, j) that contain it, ascending, built
-//      once (workgroup = pixel, thread = RoI; membership is separable: row bins of r that contain y times column bins that
-//      contain x);
+//   1. k_cover_build   per pixel, the list of the bins (r, i, j) that contain it, ascending, built once (workgroup = pixel,
+//      thread = RoI; membership is separable: row bins of r that contain y times column bins that contain x).  A workgroup
+//      counts, takes its run of the entry array with ONE atomic add on a counter (where a list lies is arbitrary, what it holds
+//      and in which order is not), then writes;
 //   2. k_grad_by_bin   Q[(r, i, j)][c] = gradOut[r][c][i][j] / n(r, i, j): the division of :123 done once per gradOut element
 //      instead of once per pixel of its bin, and the channel made the contiguous index;
 //   3. k_roipool_bwd_lists   workgroup = pixel, thread = channel: gradIn[c][y][x] = sum over the pixel's list of Q[bin][c] --
 //      the list entry is wave-uniform, the loads are coalesced along c.
 //
 // The lists live in the caller's workspace, sized for RoIs no larger than the map (R (H + 2k)(W + 2k) entries).  RoIs far larger
-// than the map can exceed that (every bin of such a RoI covers the whole map): the scan notices, steps 1c-3 do nothing and the
-// thread-per-pixel kernel, launched last and otherwise returning at once, does the work -- decided on the device, no host
-// synchronisation.
+// than the map can exceed that (every bin of such a RoI covers the whole map): the counter then ends above the capacity, steps
+// 2-3 do nothing and the thread-per-pixel kernel, launched last and otherwise returning at once, does the work -- decided on
+// the device, no host synchronisation.
+//
+// PSROIPool backward the same way (k_ps_cover_build, k_psroipool_bwd_lists): there the list belongs to a (cell, pixel) pair -- the
+// RoIs whose cell (i, j) contains the pixel, ascending -- and serves every channel (t + 1) * bin that reads that cell
+// (ps_roipool_cuda.cu:58); k_psroipool_bwd_generic tested all R RoIs per (channel, pixel) and divisor of the channel.
 #include "d2t_kernels.hpp"
 
 namespace d2t {
@@ -23,6 +28,7 @@ namespace d2t {
 namespace {
 
 constexpr int kBlk = 256;
+constexpr int kAhead = 8;                                              // list entries whose loads are in flight together (gather)
 
 // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of pixels (bijective for any grid size).
 __device__ __forceinline__ int xcd_run(int bid, int nwg) {
@@ -40,78 +46,78 @@ __device__ __forceinline__ int axis_hits(const int4* __restrict__ br, int stride
     return n;
 }
 
-// exclusive scan of one int per thread over the workgroup; returns the thread's prefix, *total = the sum
+// exclusive scan of one int per thread over the workgroup; returns the thread's prefix, *total = the sum (sh: 4 ints)
 __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total)
 {
-    const int tid = threadIdx.x;
-    sh[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < kBlk; off <<= 1) {
-        const int add = tid >= off ? sh[tid - off] : 0;
-        __syncthreads();
-        sh[tid] += add;
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
     }
-    const int incl = sh[tid];
-    *total = sh[kBlk - 1];
+    if (lane == 63) sh[wave] = incl;
     __syncthreads();
-    return incl - v;
+    const int w0 = sh[0], w1 = sh[1], w2 = sh[2], w3 = sh[3];
+    __syncthreads();
+    *total = w0 + w1 + w2 + w3;
+    return incl - v + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+}
+
+// does RoI r reach pixel (y, x) at all?  Bin edges are monotone in the bin index (DEcreasing for a RoI of negative extent, whose
+// bins run in reverse order): the overall extent is the min / max over the first and the last bin (as in k_roipool_bwd_generic).
+__device__ __forceinline__ bool roi_reaches(const int4* __restrict__ br, int kk, int y, int x)
+{
+    const int4 bf = br[0], bl = br[kk - 1];
+    const int y_lo = bf.x < bl.x ? bf.x : bl.x, y_hi = bf.y > bl.y ? bf.y : bl.y;
+    const int x_lo = bf.z < bl.z ? bf.z : bl.z, x_hi = bf.w > bl.w ? bf.w : bl.w;
+    return y >= y_lo && y < y_hi && x >= x_lo && x < x_hi;
+}
+
+typedef unsigned long long u64;
+
+// the workgroup's `total` entries: one atomic add, result broadcast (sh: 4 ints, reused)
+__device__ __forceinline__ long long block_take(u64* counter, int total, int* sh)
+{
+    __shared__ long long start;
+    if (threadIdx.x == 0) start = (long long)atomicAdd(counter, (u64)total);
+    __syncthreads();
+    const long long v = start;
+    __syncthreads();
+    return v;
 }
 
 __global__ void __launch_bounds__(kBlk)
-k_cover_count(const int32_t* __restrict__ bins, int32_t* __restrict__ counts, int R, int H, int W, int k)
+k_cover_build(const int32_t* __restrict__ bins, u64* __restrict__ counter, int2* __restrict__ heads, int32_t* __restrict__ entries,
+              long long cap, int R, int H, int W, int k)
 {
-    __shared__ int sh[kBlk];
+    __shared__ int sh[4];
     const int4* bt = reinterpret_cast<const int4*>(bins);
     const int p = blockIdx.x, y = p / W, x = p - y * W;
     int n = 0;
     for (int r = threadIdx.x; r < R; r += kBlk) {
         const int4* br = bt + (size_t)r * k * k;
+        if (!roi_reaches(br, k * k, y, x)) continue;
         const int ni = axis_hits(br, k, k, y, true);
         if (ni) n += ni * axis_hits(br, 1, k, x, false);
     }
     int total;
     block_exclusive_scan(n, sh, &total);
-    if (threadIdx.x == 0) counts[p] = total;
-}
-
-// offsets[p] = exclusive prefix of counts (in place), offsets[n] = total (saturating: a sum past INT_MAX stays there)
-__global__ void __launch_bounds__(kBlk)
-k_cover_scan(int32_t* __restrict__ offsets, int n)
-{
-    __shared__ int sh[kBlk];
-    long long base = 0;
-    for (int p0 = 0; p0 < n; p0 += kBlk) {
-        const int p = p0 + threadIdx.x;
-        const int v = p < n ? offsets[p] : 0;
-        int total;
-        const int pre = block_exclusive_scan(v, sh, &total);
-        const long long o = base + pre;
-        if (p < n) offsets[p] = o > 0x7fffffffLL ? 0x7fffffff : (int)o;
-        base += total;
-    }
-    if (threadIdx.x == 0) offsets[n] = base > 0x7fffffffLL ? 0x7fffffff : (int)base;
-}
-
-__global__ void __launch_bounds__(kBlk)
-k_cover_fill(const int32_t* __restrict__ bins, const int32_t* __restrict__ offsets, int32_t* __restrict__ entries, int cap,
-             int R, int H, int W, int k)
-{
-    __shared__ int sh[kBlk];
-    if (offsets[H * W] > cap) return;                                 // the lists do not fit: the thread-per-pixel kernel runs instead
-    const int4* bt = reinterpret_cast<const int4*>(bins);
-    const int p = blockIdx.x, y = p / W, x = p - y * W;
-    int base = offsets[p];
+    const long long start = block_take(counter, total, sh);
+    const bool fits = start + total <= cap;
+    if (threadIdx.x == 0) heads[p] = fits ? make_int2((int)start, total) : make_int2(0, 0);
+    if (!fits || total == 0) return;                                  // (no list: the thread-per-pixel kernel runs instead)
+    int base = (int)start;
     for (int r0 = 0; r0 < R; r0 += kBlk) {                            // RoIs ascending: 256 at a time, in thread order
         const int r = r0 + threadIdx.x;
         const int4* br = bt + (size_t)(r < R ? r : 0) * k * k;
         int ni = 0, nj = 0;
-        if (r < R) {
+        if (r < R && roi_reaches(br, k * k, y, x)) {
             ni = axis_hits(br, k, k, y, true);
             if (ni) nj = axis_hits(br, 1, k, x, false);
         }
-        int total;
-        int pos = base + block_exclusive_scan(ni * nj, sh, &total);
+        int pass;
+        int pos = base + block_exclusive_scan(ni * nj, sh, &pass);
         if (ni * nj) {
             for (int i = 0; i < k; ++i) {                             // (i, j) ascending
                 const int4 bi = br[i * k];
@@ -123,7 +129,102 @@ k_cover_fill(const int32_t* __restrict__ bins, const int32_t* __restrict__ offse
                 }
             }
         }
-        base += total;
+        base += pass;
+    }
+}
+
+// PSROIPool: thread = (cell, pixel), lanes along x; its list = the RoIs (ascending) whose cell contains the pixel, with the
+// cell's area.  Two walks over the RoIs: count, take a run of the entry array, write.
+__global__ void __launch_bounds__(kBlk)
+k_ps_cover_build(const int32_t* __restrict__ cells, u64* __restrict__ counter, int2* __restrict__ heads, int2* __restrict__ entries,
+                 long long cap, int R, int HW, int W, int kk)
+{
+    __shared__ int sh[4];
+    const int4* ct = reinterpret_cast<const int4*>(cells);
+    const int id = blockIdx.x * kBlk + threadIdx.x;                   // list = bin * HW + pixel
+    const bool live = id < kk * HW;
+    const int bin = live ? id / HW : 0, p = live ? id - bin * HW : 0, y = p / W, x = p - y * W;
+    int n = 0;
+    if (live)
+        for (int r0 = 0; r0 < R; r0 += kAhead) {                      // kAhead cells' bounds in flight
+            int4 cb[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) cb[u] = ct[(size_t)(r0 + u < R ? r0 + u : r0) * kk + bin];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) n += (r0 + u < R && y >= cb[u].x && y < cb[u].y && x >= cb[u].z && x < cb[u].w);
+        }
+    int total;
+    const int pre = block_exclusive_scan(n, sh, &total);
+    const long long start = block_take(counter, total, sh);
+    const bool fits = start + total <= cap;
+    if (live) heads[id] = fits ? make_int2((int)start + pre, n) : make_int2(0, 0);
+    if (!fits || !live || n == 0) return;
+    int2* dst = entries + start + pre;
+    for (int r0 = 0; r0 < R; r0 += kAhead) {
+        int4 cb[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) cb[u] = ct[(size_t)(r0 + u < R ? r0 + u : r0) * kk + bin];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u)
+            if (r0 + u < R && y >= cb[u].x && y < cb[u].y && x >= cb[u].z && x < cb[u].w)
+                *dst++ = make_int2(r0 + u, (cb[u].y - cb[u].x) * (cb[u].w - cb[u].z));
+    }
+}
+
+// gradIn[ch][y][x]: thread per (ch, pixel).  Channel ch receives from every (t, bin) with (t + 1) * bin == ch (ch == 0: bin 0 with
+// every t); bins ascending, then the list (RoIs ascending), then t -- the order of k_psroipool_bwd_generic; each term gradOut / n
+// (ps_roipool_cuda.cu:118-127 in gather form).
+template <typename T>
+__global__ void __launch_bounds__(kBlk)
+k_psroipool_bwd_lists(const T* __restrict__ gout, const u64* __restrict__ counter, const int2* __restrict__ heads,
+                      const int2* __restrict__ entries, long long cap, T* __restrict__ gin, int nT, int HW, int kk)
+{
+    if ((long long)*counter > cap) return;
+    const long long total = 1LL * nT * kk * HW;
+    for (long long i64 = (long long)blockIdx.x * kBlk + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlk) {
+        const int ch = (int)(i64 / HW), p = (int)(i64 - (long long)ch * HW);
+        T acc = T(0);
+        const int bin_lo = ch == 0 ? 0 : 1, bin_hi = ch == 0 ? 0 : kk - 1;
+        for (int bin = bin_lo; bin <= bin_hi; ++bin) {
+            int t_lo, t_hi;
+            if (ch == 0) { t_lo = 0; t_hi = nT - 1; }
+            else {
+                if (ch % bin != 0) continue;
+                const int tp1 = ch / bin;
+                if (tp1 > nT) continue;
+                t_lo = t_hi = tp1 - 1;
+            }
+            const int2 h = heads[(size_t)bin * HW + p];
+            const int end = h.x + h.y;
+            if (t_lo == t_hi) {                                       // one target: four list entries' loads in flight, added in list order
+                for (int e = h.x; e < end; e += 4) {
+                    int2 rn[4];
+                    T g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rn[u] = entries[e + u < end ? e + u : e];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) g[u] = gout[((size_t)rn[u].x * nT + t_lo) * kk + bin];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (e + u < end) acc += g[u] / static_cast<T>(rn[u].y);
+                }
+            } else {                                                  // channel 0: every target of every listed RoI, eight loads in flight
+                for (int e = h.x; e < end; ++e) {
+                    const int2 rn = entries[e];
+                    const T* gp = gout + (size_t)rn.x * nT * kk + bin;
+                    const T dn = static_cast<T>(rn.y);
+                    for (int t0 = t_lo; t0 <= t_hi; t0 += 8) {
+                        T g[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) g[u] = gp[(size_t)(t0 + u <= t_hi ? t0 + u : t0) * kk];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (t0 + u <= t_hi) acc += g[u] / dn;
+                    }
+                }
+            }
+        }
+        gin[i64] = acc;
     }
 }
 
@@ -131,11 +232,11 @@ k_cover_fill(const int32_t* __restrict__ bins, const int32_t* __restrict__ offse
 // through LDS, rows of CH contiguous channels out.
 template <typename T>
 __global__ void __launch_bounds__(kBlk)
-k_grad_by_bin(const T* __restrict__ gout, const int32_t* __restrict__ bins, const int32_t* __restrict__ gate, int cap,
+k_grad_by_bin(const T* __restrict__ gout, const int32_t* __restrict__ bins, const u64* __restrict__ counter, long long cap,
               T* __restrict__ q, int R, int C, int kk, int k, int CH)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    if (*gate > cap) return;
+    if ((long long)*counter > cap) return;
     T* tile = reinterpret_cast<T*>(lds_raw);                          // [CH][kk + 1]
     const int4* bt = reinterpret_cast<const int4*>(bins);
     const int chunks = (C + CH - 1) / CH;
@@ -157,20 +258,33 @@ k_grad_by_bin(const T* __restrict__ gout, const int32_t* __restrict__ bins, cons
 // tid, tid + 256, tid + 512, tid + 768 of each group of 1024.
 template <typename T>
 __global__ void __launch_bounds__(kBlk)
-k_roipool_bwd_lists(const T* __restrict__ q, const int32_t* __restrict__ offsets, const int32_t* __restrict__ entries, int cap,
-                    T* __restrict__ gin, int C, int HW)
+k_roipool_bwd_lists(const T* __restrict__ q, const u64* __restrict__ counter, const int2* __restrict__ heads,
+                    const int32_t* __restrict__ entries, long long cap, T* __restrict__ gin, int C, int HW)
 {
-    if (offsets[HW] > cap) return;
-    const int p = xcd_run(blockIdx.x, HW);                          // neighbouring pixels (nearly the same lists) share an L2
-    const int beg = offsets[p], end = offsets[p + 1];
+    if ((long long)*counter > cap) return;
+    const int p = xcd_run(blockIdx.x, HW);                            // neighbouring pixels (nearly the same lists) share an L2
+    const int2 h = heads[p];
+    const int beg = h.x, end = h.x + h.y;
     for (int c0 = 0; c0 < C; c0 += 4 * kBlk) {
         const int c = c0 + threadIdx.x;
         T acc[4] = {T(0), T(0), T(0), T(0)};
-        for (int e = beg; e < end; ++e) {
-            const T* row = q + (size_t)entries[e] * C + c;
+        bool has[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                if (c + m * kBlk < C) acc[m] += row[m * kBlk];
+        for (int m = 0; m < 4; ++m) has[m] = c + m * kBlk < C;
+        for (int e = beg; e < end; e += kAhead) {                     // kAhead list entries' loads in flight, added in list order
+            T v[kAhead][4];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const T* row = q + (size_t)entries[e + u < end ? e + u : e] * C + c;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[u][m] = has[m] ? row[m * kBlk] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u)
+                if (e + u < end) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] += v[u][m];
+                }
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -181,20 +295,35 @@ k_roipool_bwd_lists(const T* __restrict__ q, const int32_t* __restrict__ offsets
 inline size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 
 struct ListsLayout {
-    size_t bins, offsets, entries, q, total;
+    size_t bins, counter, heads, entries, q, total;
     long long cap;
 };
 
+inline long long lists_cap(int R, int H, int W, int k) { return 1LL * R * (H + 2LL * k) * (W + 2LL * k); }
+
 template <typename T>
-ListsLayout lists_layout(int R, int C, int H, int W, int k)
+ListsLayout lists_layout(int R, int C, int H, int W, int k)          // ROIPool: bins | counter | heads[HW] | entries | Q
 {
     ListsLayout L;
-    L.cap = 1LL * R * (H + 2LL * k) * (W + 2LL * k);
+    L.cap = lists_cap(R, H, W, k);
     L.bins = 0;
-    L.offsets = up256((size_t)R * k * k * 16);
-    L.entries = L.offsets + up256(((size_t)H * W + 1) * 4);
+    L.counter = up256((size_t)R * k * k * 16);
+    L.heads = L.counter + 256;
+    L.entries = L.heads + up256((size_t)H * W * 8);
     L.q = L.entries + up256((size_t)L.cap * 4);
     L.total = L.q + up256((size_t)R * C * k * k * sizeof(T));
+    return L;
+}
+
+inline ListsLayout ps_lists_layout(int R, int H, int W, int k)       // PSROIPool: cells | counter | heads[kk HW] | entries (r, n)
+{
+    ListsLayout L;
+    L.cap = lists_cap(R, H, W, k);
+    L.bins = 0;
+    L.counter = up256((size_t)R * k * k * 16);
+    L.heads = L.counter + 256;
+    L.entries = L.heads + up256((size_t)k * k * H * W * 8);
+    L.q = L.total = L.entries + up256((size_t)L.cap * 8);
     return L;
 }
 
@@ -204,9 +333,8 @@ template <typename T>
 bool roipool_bwd_lists_supported(int R, int C, int H, int W, int k)
 {
     if (R < 1 || C < 1 || H < 1 || W < 1 || k < 1) return false;
-    const long long cap = 1LL * R * (H + 2LL * k) * (W + 2LL * k);
-    return cap < 0x4000000LL && 1LL * R * k * k < 0x7fffffffLL / 4 && fits_i32(1LL * R * C * k * k) && fits_i32(1LL * C * H * W) &&
-           (size_t)k * k * sizeof(T) <= 16 * 1024;
+    return lists_cap(R, H, W, k) < 0x4000000LL && 1LL * R * k * k < 0x7fffffffLL / 4 && fits_i32(1LL * R * C * k * k) &&
+           fits_i32(1LL * C * H * W) && (size_t)k * k * sizeof(T) <= 16 * 1024;
 }
 
 template <typename T>
@@ -221,29 +349,63 @@ int roipool_bwd_lists(const T* gout, const T* rois, T* gin, void* ws, int R, int
     const ListsLayout L = lists_layout<T>(R, C, H, W, k);
     unsigned char* base = static_cast<unsigned char*>(ws);
     int32_t* bins = reinterpret_cast<int32_t*>(base + L.bins);
-    int32_t* offsets = reinterpret_cast<int32_t*>(base + L.offsets);
+    u64* counter = reinterpret_cast<u64*>(base + L.counter);
+    int2* heads = reinterpret_cast<int2*>(base + L.heads);
     int32_t* entries = reinterpret_cast<int32_t*>(base + L.entries);
     T* q = reinterpret_cast<T*>(base + L.q);
-    const int HW = H * W, kk = k * k, cap = (int)L.cap;
+    const int HW = H * W, kk = k * k;
     int rc = roipool_bins<T>(rois, bins, R, H, W, k, st);
     if (rc != D2T_OK) return rc;
-    hipLaunchKernelGGL(k_cover_count, dim3(HW), dim3(kBlk), 0, st, bins, offsets, R, H, W, k);
-    hipLaunchKernelGGL(k_cover_scan, dim3(1), dim3(kBlk), 0, st, offsets, HW);
-    hipLaunchKernelGGL(k_cover_fill, dim3(HW), dim3(kBlk), 0, st, bins, offsets, entries, cap, R, H, W, k);
+    if (hipMemsetAsync(counter, 0, sizeof(u64), st) != hipSuccess) return launch_status();
+    hipLaunchKernelGGL(k_cover_build, dim3(HW), dim3(kBlk), 0, st, bins, counter, heads, entries, L.cap, R, H, W, k);
     int CH = 64;
     while (CH > 1 && (size_t)CH * (kk + 1) * sizeof(T) > 32 * 1024) CH >>= 1;
     hipLaunchKernelGGL(k_grad_by_bin<T>, dim3(R * ((C + CH - 1) / CH)), dim3(kBlk), (size_t)CH * (kk + 1) * sizeof(T), st,
-                       gout, bins, offsets + HW, cap, q, R, C, kk, k, CH);
-    hipLaunchKernelGGL(k_roipool_bwd_lists<T>, dim3(HW), dim3(kBlk), 0, st, q, offsets, entries, cap, gin, C, HW);
+                       gout, bins, counter, L.cap, q, R, C, kk, k, CH);
+    hipLaunchKernelGGL(k_roipool_bwd_lists<T>, dim3(HW), dim3(kBlk), 0, st, q, counter, heads, entries, L.cap, gin, C, HW);
     rc = launch_status();
     if (rc != D2T_OK) return rc;
-    return roipool_bwd_generic_gated<T>(gout, bins, gin, offsets + HW, cap, R, C, H, W, k, st);   // runs only if the lists overflowed
+    return roipool_bwd_generic_gated<T>(gout, bins, gin, counter, L.cap, R, C, H, W, k, st);   // runs only if the lists overflowed
+}
+
+bool psroipool_bwd_lists_supported(int R, int nT, int H, int W, int k)
+{
+    if (R < 1 || nT < 1 || H < 1 || W < 1 || k < 1) return false;
+    return lists_cap(R, H, W, k) < 0x4000000LL && 1LL * R * k * k < 0x7fffffffLL / 4 && fits_i32(1LL * R * nT * k * k) &&
+           fits_i32(1LL * nT * k * k * H * W) && 1LL * k * k * H * W < 0x8000000LL;
+}
+
+size_t psroipool_bwd_lists_ws_bytes(int R, int nT, int H, int W, int k)
+{
+    return psroipool_bwd_lists_supported(R, nT, H, W, k) ? ps_lists_layout(R, H, W, k).total : 0;
+}
+
+template <typename T>
+int psroipool_bwd_lists(const T* gout, const T* rois, T* gin, void* ws, int R, int nT, int H, int W, int k, hipStream_t st)
+{
+    const ListsLayout L = ps_lists_layout(R, H, W, k);
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    int32_t* cells = reinterpret_cast<int32_t*>(base + L.bins);
+    u64* counter = reinterpret_cast<u64*>(base + L.counter);
+    int2* heads = reinterpret_cast<int2*>(base + L.heads);
+    int2* entries = reinterpret_cast<int2*>(base + L.entries);
+    const int HW = H * W, kk = k * k;
+    int rc = psroipool_bins<T>(rois, cells, R, H, W, k, st);
+    if (rc != D2T_OK) return rc;
+    if (hipMemsetAsync(counter, 0, sizeof(u64), st) != hipSuccess) return launch_status();
+    hipLaunchKernelGGL(k_ps_cover_build, dim3((kk * HW + kBlk - 1) / kBlk), dim3(kBlk), 0, st, cells, counter, heads, entries, L.cap, R, HW, W, kk);
+    hipLaunchKernelGGL(k_psroipool_bwd_lists<T>, dim3(grid_for(1LL * nT * kk * HW, kBlk, 256 * 32)), dim3(kBlk), 0, st,
+                       gout, counter, heads, entries, L.cap, gin, nT, HW, kk);
+    rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    return psroipool_bwd_generic_gated<T>(gout, cells, gin, counter, L.cap, R, nT, H, W, k, st);
 }
 
 #define D2T_INSTANTIATE_LISTS(T)                                                  \
     template bool roipool_bwd_lists_supported<T>(int, int, int, int, int);         \
     template size_t roipool_bwd_lists_ws_bytes<T>(int, int, int, int, int);        \
-    template int roipool_bwd_lists<T>(const T*, const T*, T*, void*, int, int, int, int, int, hipStream_t);
+    template int roipool_bwd_lists<T>(const T*, const T*, T*, void*, int, int, int, int, int, hipStream_t); \
+    template int psroipool_bwd_lists<T>(const T*, const T*, T*, void*, int, int, int, int, int, hipStream_t);
 D2T_INSTANTIATE_LISTS(float)
 D2T_INSTANTIATE_LISTS(double)
 

@@ -12,7 +12,7 @@
  *   d2t_corr_bwd_*       <- pointwise_correlation_backward  pointwise_correlation/pointwise_correlation.cpp:36-48
  *                           (launcher pointwise_correlation_cuda.cu:214-249)
  *                           (d2t_corr_bwd_workspace_bytes is non-zero OUTSIDE the tuned envelope and for f64: with that
- *                           scratch the blocked kernels run, without it the thread-per-element ones -- same values)
+ *                           scratch the tiled / blocked kernels run, without it the thread-per-element ones -- same values)
  *   d2t_roipool_fwd_*    <- roipool_forward                 roipool/roipool.cpp:22-32   (roipool_cuda.cu:130-157)
  *   d2t_roipool_bwd_*    <- roipool_backward                roipool/roipool.cpp:35-45   (roipool_cuda.cu:160-190)
  *   d2t_psroipool_fwd_*  <- ps_roipool_forward              ps_roipool/ps_roipool.cpp:23-34 (ps_roipool_cuda.cu:144-174)
@@ -69,14 +69,17 @@ const char* d2t_error_string(int code);
 
 /* The tuned envelope and what leaving it costs.  The gfx950-tuned kernels cover what the reference model uses
  * (cfg/default.yaml:48,50: D_MAX 8, K 7; correlation_tracker.py:26: stride 1): correlation d_max = 8, stride 1, W >= 20;
- * pooling k = 7; float32.  Everything else -- and all of float64 -- runs type-generic kernels in the reference's order (the
- * correlation: d2t_corr_blocked.hip, four cells per thread forward, gradOut staged in LDS backward, bit-identical to the
- * thread-per-element kernels D2T_IMPL_GENERIC selects; pooling: one thread per output element): same results, measured on an
- * MI355X (tools/envelope_cost.py, us forward / backward):
- *   correlation B=8 C=256 38x63   tuned 46 / 74     d_max=7: 546 / 1,351     stride 2: 571 / 1,083     f64: 1,230 / 2,072
- *                                 (thread-per-element kernels, D2T_IMPL_GENERIC: 668 / 6,743, 787 / 2,539, 1,230 / 11,216)
- *   ROIPool R=300 C=1024 38x63    tuned 31 / 72     k=6: 168 / 2,346         f64: 270 / 3,105
- *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 510            f64: 25 / 640
+ * pooling k = 7; float32.  Everything else -- and all of float64 -- runs type-generic kernels in the reference's order whose
+ * results are bit-identical to the thread-per-element kernels D2T_IMPL_GENERIC selects (tested), in two tiers: the default
+ * dispatch takes kernels that share the work the anchor repeats per thread (correlation f32, d_max <= 14: d2t_corr_blocked.hip --
+ * forward tiles of 4 x 8 pixels with the FM1 window in LDS, backward four pixels x four channels per thread from zero-padded row
+ * copies; pooling backward: d2t_pool_lists.hip -- per-pixel lists of the bins / RoIs that contain the pixel, built once and shared
+ * by all channels), D2T_IMPL_GENERIC the thread-per-element anchors.  Measured on an MI355X (tools/envelope_cost.py, us forward /
+ * backward; thread-per-element anchor in brackets):
+ *   correlation B=8 C=256 38x63   tuned 46 / 74     d_max=7: 125 / 305 (668 / 6,743)   stride 2: 127 / 229 (787 / 2,539)
+ *                                                   f64: 1,217 / 2,068 (1,230 / 11,216)
+ *   ROIPool R=300 C=1024 38x63    tuned 31 / 65     k=6: 167 / 169 (168 / 2,346)       f64: 269 / 294 (270 / 3,105)
+ *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 131 (18 / 510)           f64: 25 / 184 (25 / 640)
  * (the Python wrappers warn once when a float32 call leaves the envelope under D2T_IMPL_AUTO).
  *
  * Implementation selector of the f32 entry points (per call, no global state):
@@ -157,7 +160,10 @@ int d2t_corr_bwd_levels_f32(int n_levels, const float* const* gout, const float*
                             int layout, long long batch_stride,
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
 
-/* ---------------- ROIPool (average) ---------------- */
+/* ---------------- ROIPool (average) ----------------
+ * Backward outside the tuned envelope (k != 7, f64): d2t_roipool_bwd_workspace_bytes covers the per-pixel bin lists and the
+ * (bin, channel) copy of gradOut / n of d2t_pool_lists.hip (about the size of gradOut); a caller that passes only the R k^2 16
+ * bytes of the bin table gets the thread-per-pixel kernel -- same values, ~14x slower.  PSROIPool likewise. */
 size_t d2t_roipool_fwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size);
 size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size);
 

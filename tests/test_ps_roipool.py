@@ -214,6 +214,34 @@ def test_nonfinite_gradout_gemm_backward(case):
     torch.testing.assert_close(got[fin], want[fin], rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case", [(300, 21, 38, 63, 6, "random"), (40, 31, 20, 31, 3, "random"), (17, 5, 9, 14, 14, "random"), (9, 3, 7, 5, 1, "random"),
+                                  (300, 4, 38, 63, 8, "adversarial"), (520, 9, 12, 17, 2, "random"), (12, 6, 20, 20, 3, "huge")], ids=str)
+def test_outside_the_envelope_backward_equals_generic_kernel(case, dtype):
+    """Cell counts other than 7 (and all of f64) take the per-(cell, pixel) RoI lists of d2t_pool_lists.hip under the default dispatch:
+    the same terms gradOut / n in the same order (bins ascending, RoIs ascending, targets ascending) as the thread-per-pixel kernel
+    (ps_roipool_cuda.cu:118-127, gather form): bit-identical to D2T_IMPL_GENERIC, which test_matches_oracle pins to the oracle.
+    "huge": RoIs many times the map, whose lists exceed the workspace -- the device-side fallback.  Non-finite gradOut included."""
+    from detect_to_track.models import _ext
+    R, nT, H, W, k, kind = case
+    rng = np.random.default_rng(R * 31 + k)
+    if kind == "random":
+        rois = random_rois(R, k)
+    elif kind == "adversarial":
+        rois = np.resize(ADVERSARIAL_ROIS, (R, 4))
+    else:
+        rois = np.concatenate([rng.random((R, 2)), 20 + 30 * rng.random((R, 2))], axis=1)
+    gout = rng.standard_normal((R, nT, k, k))
+    gout[0, 0, 0, 0] = np.inf
+    gout[R - 1, nT - 1, k - 1, k - 1] = np.nan
+    g, r = _t(gout.astype(dtype)), _t(np.asarray(rois).astype(dtype))
+    got = _ext.ps_roipool_backward(g, r, H, W, 0)
+    want = _ext.ps_roipool_backward(g, r, H, W, 1)
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    fin = ~torch.isnan(want)
+    assert torch.equal(got[fin], want[fin])
+
+
 def test_channel_collisions_and_unused_channels():
     """(t+1)*(i*k+j) is many-to-one (reference ps_roipool_cuda.cu:58): for nT=2,k=3 only 13 of 18
     channels are ever read; the gradient of the other 5 must be exactly zero."""
