@@ -64,6 +64,28 @@ def test_argument_validation_without_device(native):
     assert L.d2t_roipool_bins_f32(None, None, 2, 5, 5, 3, None) == EINVAL
 
 
+def test_workspace_queries_cover_the_second_kernel_tier(native):
+    """Outside the tuned envelope the *_workspace_bytes queries ask for the scratch of the kernels the default dispatch takes there
+    (include/d2t_ops.h: zero-padded map copies + gradOut by displaced pixel for the correlation backward; bin lists + gradOut / n by
+    (bin, channel) for the pooling backward) -- host arithmetic only, no device needed.  Inside the envelope nothing changes."""
+    L = native.lib
+    B, C, H, W = 8, 256, 38, 63
+    cells7 = 15 * 15
+    tiled = L.d2t_corr_bwd_workspace_bytes(B, C, H, W, 7, 1, 4)
+    assert tiled >= B * H * W * cells7 * 4 + 2 * B * C * H * (W + 14) * 4        # gradOut re-indexed + both maps with padded rows
+    assert L.d2t_corr_bwd_workspace_bytes(B, C, H, W, 20, 1, 4) >= B * H * W * 41 * 41 * 4   # d_max > 14: the blocked kernels (no map copies)
+    assert L.d2t_corr_bwd_workspace_bytes(B, C, H, W, 20, 1, 4) < B * H * W * 41 * 41 * 4 + 2 * B * C * H * W * 4
+    assert L.d2t_corr_bwd_workspace_bytes(B, C, H, W, 7, 1, 8) >= B * H * W * cells7 * 8     # f64: blocked
+    R, Cp, k = 300, 1024, 6
+    lists = L.d2t_roipool_bwd_workspace_bytes(R, Cp, H, W, k, 4)
+    assert lists >= R * Cp * k * k * 4 + R * (H + 2 * k) * (W + 2 * k) * 4 + R * k * k * 16
+    assert L.d2t_roipool_bwd_workspace_bytes(R, Cp, H, W, k, 8) >= R * Cp * k * k * 8
+    ps = L.d2t_psroipool_bwd_workspace_bytes(R, 21, H, W, k, 4)
+    assert ps >= R * (H + 2 * k) * (W + 2 * k) * 8 + k * k * H * W * 8
+    # k = 7, f32: the tuned kernels' own (much smaller) scratch -- the lists are not asked for
+    assert L.d2t_roipool_bwd_workspace_bytes(R, Cp, H, W, 7, 4) < R * Cp * 49 * 4
+
+
 def test_header_cites_the_reference_binding():
     # every replaced pybind function is named with its file:line
     for token in ("pointwise_correlation.cpp:23-33", "pointwise_correlation.cpp:36-48", "roipool.cpp:22-32",
