@@ -91,12 +91,12 @@ constexpr int RF_ACTIVE = 980;                // 20 * 49 = 10 * 98 = 5 * 196
 constexpr int RF_RC = 240;                    // RoIs whose geometry is staged in LDS at a time (a multiple of 20)
 
 struct SatLayout { int LD, plane; size_t bytes; };
-inline SatLayout sat_layout(int CG, int H, int W)
+inline SatLayout sat_layout(int CG, int H, int W, int geo = GEO8)
 {
     SatLayout L;
     L.LD = (W + 1) | 1;
     L.plane = (H + 1) * L.LD;
-    L.bytes = (size_t)CG * L.plane * 8 + prefix_scratch_bytes(CG, H, W) + (size_t)RF_RC * GEO8;
+    L.bytes = (size_t)CG * L.plane * 8 + prefix_scratch_bytes(CG, H, W) + (size_t)RF_RC * geo;
     return L;
 }
 
@@ -201,11 +201,17 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const float* __restrict__ rois, 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int S2_THREADS = 1024;             // two workgroups per CU (45 KB of LDS each); 512 threads x 4 per CU measured 35.5 us against 32.8
 constexpr int S2_ACTIVE = 980;               // 20 RoIs x 49 bins per pass
+constexpr int S2_MAXK = 16;                  // run-time bin counts the interleaved kernel takes (4k bytes of geometry per RoI <= 64)
 
+// KTT = 7: the model's bin count, the thread -> (RoI slot, bin) map in compile-time constants; KTT = 0: any k <= S2_MAXK, the same
+// map computed once per thread from the run-time k (4k bytes of geometry per RoI instead of 32).
+template <int KTT>
 __global__ void __launch_bounds__(S2_THREADS)
 k_roipool_fwd_sat2(const float* __restrict__ fm, const float* __restrict__ rois, float* __restrict__ out,
-                   int R, int C, int H, int W, int LD, int plane, int rois_per_wg)
+                   int R, int C, int H, int W, int LD, int plane, int rois_per_wg, int k_rt)
 {
+    const int kt = KTT ? KTT : k_rt, kk = kt * kt;
+    const int geo = KTT ? GEO8 : 4 * kt;                             // bytes of geometry per RoI
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double* sat = reinterpret_cast<double*>(lds_raw);                // [H+1][LD][2]
     double* scr = sat + (size_t)2 * plane;                           // prefix scratch
@@ -240,29 +246,29 @@ k_roipool_fwd_sat2(const float* __restrict__ fm, const float* __restrict__ rois,
     prefix2d(sat + (size_t)(LD + 1) * 2, scr, 2, H, W, LD, 1, tid, S2_THREADS, 2);
 
     // ---- outputs: thread t < 980 owns bin t mod 49 of RoI slot t / 49 (20 RoIs per pass), both channels
-    constexpr int RPP = S2_ACTIVE / KK;
-    const bool worker = tid < S2_ACTIVE;
-    const int rr0 = tid / KK, bin = tid - rr0 * KK, i = bin / KT, j = bin - i * KT;
+    const int RPP = KTT ? S2_ACTIVE / KK : S2_THREADS / kk;          // RoIs per pass
+    const bool worker = tid < RPP * kk;
+    const int rr0 = tid / kk, bin = tid - rr0 * kk, i = bin / kt, j = bin - i * kt;
     const bool live0 = worker && c0 < C, live1 = worker && c0 + 1 < C;
     const f64x2* S = reinterpret_cast<const f64x2*>(sat);
     const unsigned char* geoB = reinterpret_cast<const unsigned char*>(geoL) + 2 * i;
-    const int joff = 2 * KT + 2 * j - 2 * i;
+    const int joff = 2 * kt + 2 * j - 2 * i;
     for (int rb = r_lo; rb < r_hi; rb += RF_RC) {
         const int rc = r_hi - rb < RF_RC ? r_hi - rb : RF_RC;
         __syncthreads();                                             // previous records consumed
         unsigned char* geoW = reinterpret_cast<unsigned char*>(geoL);
-        for (int e = tid; e < rc * KT; e += S2_THREADS) {            // bin row q and bin column q of RoI rb + e/7
-            const int rr = e / KT, qq = e - rr * KT;
-            const Bounds bq = roi_bin<float>(rois + 4 * (size_t)(rb + rr), qq, qq, H, W, KT);
-            *reinterpret_cast<unsigned short*>(geoW + rr * GEO8 + 2 * qq) = (unsigned short)(bq.i0 | (bq.i1 << 8));
-            *reinterpret_cast<unsigned short*>(geoW + rr * GEO8 + 2 * KT + 2 * qq) = (unsigned short)(bq.j0 | (bq.j1 << 8));
+        for (int e = tid; e < rc * kt; e += S2_THREADS) {            // bin row q and bin column q of RoI rb + e/k
+            const int rr = e / kt, qq = e - rr * kt;
+            const Bounds bq = roi_bin<float>(rois + 4 * (size_t)(rb + rr), qq, qq, H, W, kt);
+            *reinterpret_cast<unsigned short*>(geoW + rr * geo + 2 * qq) = (unsigned short)(bq.i0 | (bq.i1 << 8));
+            *reinterpret_cast<unsigned short*>(geoW + rr * geo + 2 * kt + 2 * qq) = (unsigned short)(bq.j0 | (bq.j1 << 8));
         }
         __syncthreads();
         if (!live0) continue;
-        float* dst = out + ((size_t)(rb + rr0) * C + c0) * KK + bin;
-        const size_t dstep = (size_t)RPP * C * KK;
+        float* dst = out + ((size_t)(rb + rr0) * C + c0) * kk + bin;
+        const size_t dstep = (size_t)RPP * C * kk;
         auto pool = [&](int rr, float* d, bool on) {
-            const unsigned char* gr = geoB + (on ? rr : rr0) * GEO8;
+            const unsigned char* gr = geoB + (on ? rr : rr0) * geo;
             const unsigned pi = *reinterpret_cast<const unsigned short*>(gr);
             const unsigned pj = *reinterpret_cast<const unsigned short*>(gr + joff);
             const int i0 = pi & 255, i1 = pi >> 8, j0 = pj & 255, j1 = pj >> 8;
@@ -283,7 +289,7 @@ k_roipool_fwd_sat2(const float* __restrict__ fm, const float* __restrict__ rois,
                         for (int x = j0; x < j1; ++x) acc += chp[y * W + x];
                     res = acc / (float)n;
                 }
-                if (on && (c == 0 || live1)) d[c * KK] = res;
+                if (on && (c == 0 || live1)) d[c * kk] = res;
             }
         };
         for (int rr = rr0; rr < rc; rr += 2 * RPP, dst += 2 * dstep) {
@@ -304,18 +310,25 @@ static int sat_cg(int C, int H, int W)
     return sat_layout(1, H, W).bytes <= (size_t)LDS_MAX ? 1 : 0;
 }
 
+// k = 7: every channel grouping; other k <= S2_MAXK: the interleaved two-channel kernel with the bin count at run time
+static bool sat2_anyk(int C, int H, int W, int k)
+{
+    return k >= 1 && k <= S2_MAXK && sat_layout(2, H, W, 4 * k > GEO8 ? 4 * k : GEO8).bytes <= (size_t)LDS_MAX;
+}
+
 bool roipool_fwd_supported(int R, int C, int H, int W, int k)
 {
-    return k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && H <= 255 && W <= 255 && sat_cg(C, H, W) > 0;
+    if (!(R >= 1 && C >= 1 && H >= 1 && W >= 1 && H <= 255 && W <= 255)) return false;
+    return k == KT ? sat_cg(C, H, W) > 0 : sat2_anyk(C, H, W, k);
 }
 
 size_t roipool_fwd_ws_bytes(int, int, int, int, int) { return 0; }
 
-int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int,
+int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int k,
                     void*, hipStream_t st)
 {
-    const int CG = sat_cg(C, H, W);
-    const SatLayout L = sat_layout(CG, H, W);
+    const int CG = k == KT ? sat_cg(C, H, W) : 2;
+    const SatLayout L = sat_layout(CG, H, W, k == KT || 4 * k < GEO8 ? GEO8 : 4 * k);
     const int gx = (C + CG - 1) / CG;
     int split = (256 + gx - 1) / gx;                                 // enough workgroups for every CU
     const int max_split = (R + 63) / 64;
@@ -330,9 +343,14 @@ int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C
                            L.LD, L.plane, per);                                                          \
     }
     static const int inter = lab_env_int("D2T_SAT_INTERLEAVED", 1);   // -DD2T_LAB only
+    if (k != KT) {                                                   // any other bin count: the same kernel, k at run time
+        D2T_ENSURE_DYNAMIC_LDS(k_roipool_fwd_sat2<0>, LDS_MAX);
+        hipLaunchKernelGGL(k_roipool_fwd_sat2<0>, grid, dim3(S2_THREADS), L.bytes, st, fm, rois, out, R, C, H, W, L.LD, L.plane, per, k);
+        return launch_status();
+    }
     if (CG == 2 && inter) {
-        D2T_ENSURE_DYNAMIC_LDS(k_roipool_fwd_sat2, LDS_MAX);
-        hipLaunchKernelGGL(k_roipool_fwd_sat2, grid, dim3(S2_THREADS), L.bytes, st, fm, rois, out, R, C, H, W, L.LD, L.plane, per);
+        D2T_ENSURE_DYNAMIC_LDS(k_roipool_fwd_sat2<KT>, LDS_MAX);
+        hipLaunchKernelGGL(k_roipool_fwd_sat2<KT>, grid, dim3(S2_THREADS), L.bytes, st, fm, rois, out, R, C, H, W, L.LD, L.plane, per, KT);
         return launch_status();
     }
     if (CG == 4) D2T_LAUNCH_SAT(4) else if (CG == 2) D2T_LAUNCH_SAT(2) else D2T_LAUNCH_SAT(1)

@@ -34,19 +34,20 @@ def _outside_envelope(kind: str, why: str, factor: str) -> None:
         return
     _ENVELOPE_WARNED.add(kind)
     import warnings
-    warnings.warn(f"detect_to_track {kind}: {why} is outside the gfx950-tuned kernels' envelope; the type-generic kernels run "
-                  f"instead (same results, about {factor} slower at the model's shapes)", RuntimeWarning, stacklevel=3)
+    warnings.warn(f"detect_to_track {kind}: {why} is outside the gfx950-tuned kernels' envelope; reference-order kernels run "
+                  f"instead (same results; at the model's shapes: {factor})", RuntimeWarning, stacklevel=3)
 
 
 def _check_corr_envelope(x: Tensor, d_max: int, stride: int, impl: int) -> None:
     if x.dtype == torch.float32 and impl == _native.IMPL_AUTO and x.numel() and (d_max != 8 or stride != 1 or x.shape[-1] < 20):
         _outside_envelope("PointwiseCorrelation", f"d_max = {d_max}, stride = {stride}, W = {x.shape[-1]} (tuned: d_max = 8, stride 1, W >= 20)",
-                          "3x (forward) / 3-4x (backward)")
+                          "about 3x (forward) / 3-4x (backward) slower")
 
 
 def _check_pool_envelope(kind: str, x: Tensor, k: int, impl: int) -> None:
     if x.dtype == torch.float32 and impl == _native.IMPL_AUTO and x.numel() and k != 7:
-        _outside_envelope(kind, f"r_hw = {k} (tuned: 7)", "1-5x (forward) / 3-4x (backward)")
+        fwd = "the forward as fast for r_hw <= 16, 5x slower above" if kind == "ROIPool" else "the forward as fast"
+        _outside_envelope(kind, f"r_hw = {k} (tuned: 7)", f"{fwd}; the backward 2.5-4x")
 
 
 def _check_input(x: Tensor, name: str) -> None:

@@ -78,7 +78,8 @@ const char* d2t_error_string(int code);
  * backward; thread-per-element anchor in brackets):
  *   correlation B=8 C=256 38x63   tuned 46 / 74     d_max=7: 125 / 305 (668 / 6,743)   stride 2: 127 / 229 (787 / 2,539)
  *                                                   f64: 1,217 / 2,068 (1,230 / 11,216)
- *   ROIPool R=300 C=1024 38x63    tuned 31 / 65     k=6: 167 / 169 (168 / 2,346)       f64: 269 / 294 (270 / 3,105)
+ *   ROIPool R=300 C=1024 38x63    tuned 31 / 65     k=6: 29 / 166 (168 / 2,346)        f64: 264 / 299 (270 / 3,105)
+ *                                 (forward: the summed-area kernel takes any k <= 16 -- within 1e-5 of the reference like k = 7)
  *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 131 (18 / 510)           f64: 25 / 184 (25 / 640)
  * (the Python wrappers warn once when a float32 call leaves the envelope under D2T_IMPL_AUTO).
  *

@@ -6,7 +6,7 @@ the CPU oracle, the reference-generated golden fixtures and the reference's kern
 Bit-exact: integer bin bounds {i0,i1,j0,j1}, the NaN pattern of empty bins, and the FORWARD values
 of the type-generic kernel (the reference's row-major running sum and IEEE divide,
 roipool_cuda.cu:56-61; it also serves every call with fewer than 32 RoIs under impl = auto).
-The tuned forward (>= 32 RoIs) reads summed-area tables: the exactly rounded bin sum instead of the
+The tuned forward (>= 32 RoIs, k <= 16) reads summed-area tables: the exactly rounded bin sum instead of the
 reference's f32 running sum, held to |delta| <= 1e-5 abs/rel (BASELINE.json) with the NaN pattern
 bit-exact.  Backward: |delta| <= 1e-5 -- the reference sums with atomics in undefined order.
 """
@@ -85,6 +85,8 @@ CASES = [  # (R, C, H, W, k)
     # backward as a GEMM (W <= 128): 8 column tiles; 300 RoIs on a 5-row map (every bin row of a RoI contains
     # the same map rows: up to 49 slots per RoI and row); channels not a multiple of the 32 of a task
     (37, 19, 21, 120, 7), (300, 33, 5, 40, 7), (270, 45, 38, 63, 7),
+    # bin counts other than 7 with >= 32 RoIs: the summed-area forward with k at run time (k <= 16), bin lists in the backward
+    (40, 6, 20, 33, 6), (64, 5, 38, 63, 3), (33, 4, 38, 63, 14), (50, 3, 30, 40, 16), (35, 2, 12, 12, 17), (300, 7, 38, 63, 1),
 ]
 
 
@@ -99,10 +101,10 @@ def test_matches_oracle(case, dtype, impl, oracle):
     fm = rng.random((C, H, W)).astype(dtype)
     gout = rng.random((R, C, k, k)).astype(dtype)
     tol = TOL32 if dtype == np.float32 else TOL64
-    if impl == 2 and (dtype == np.float64 or k != 7):
-        pytest.skip("the tuned kernels are f32, k = 7")
+    if impl == 2 and (dtype == np.float64 or k > 16):
+        pytest.skip("the tuned kernels are f32 (forward: k <= 16; backward: k = 7, else the bin lists)")
     out = _n(_ext.roipool_forward(_t(fm), _t(rois), k, impl))
-    tuned_fwd = dtype == np.float32 and k == 7 and (impl == 2 or (impl == 0 and R >= 32))
+    tuned_fwd = dtype == np.float32 and k <= 16 and (impl == 2 or (impl == 0 and R >= 32))
     _assert_fwd(out, oracle.roipool_fwd(fm, rois, k), exact=not tuned_fwd)
     gin = _n(_ext.roipool_backward(_t(gout), _t(rois), H, W, impl))
     np.testing.assert_allclose(gin, oracle.roipool_bwd(gout, rois, H, W), **tol)
@@ -222,6 +224,30 @@ def test_outside_the_envelope_backward_equals_generic_kernel(case, dtype):
     assert torch.equal(torch.isnan(got), torch.isnan(want))
     fin = ~torch.isnan(want)
     assert torch.equal(got[fin], want[fin])
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 8, 9, 11, 14, 16])
+def test_forward_any_bin_count_summed_area_tables(k):
+    """Bin counts 1..16 other than 7 run the interleaved summed-area kernel with k at run time (d2t_pool_tuned.hip,
+    k_roipool_fwd_sat2<0>): NaN pattern of the generic kernel (empty bins: 0/0, roipool_cuda.cu:61) bit for bit, values within 1e-5;
+    adversarial + random RoIs, an odd channel count, and a map with Inf / NaN in it (a poisoned table: the affected bins are redone in the
+    reference's form, so they match the generic kernel's non-finite pattern exactly)."""
+    from detect_to_track.models import _ext
+    R, C, H, W = 90, 5, 38, 63
+    rng = np.random.default_rng(k)
+    rois = np.concatenate([np.asarray(ADVERSARIAL_ROIS, np.float32), np.asarray(NEGATIVE_ROIS, np.float32),
+                           random_rois(R - len(ADVERSARIAL_ROIS) - len(NEGATIVE_ROIS), k)])
+    fm = rng.standard_normal((C, H, W)).astype(np.float32)
+    for poison in (False, True):
+        if poison:
+            fm[1, 7, 9] = np.inf; fm[3, 30, 50] = np.nan; fm[4, 0, 0] = -np.inf
+        got = _n(_ext.roipool_forward(_t(fm), _t(rois), k, 0))
+        want = _n(_ext.roipool_forward(_t(fm), _t(rois), k, 1))
+        assert got.shape == (R, C, k, k)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_array_equal(np.isinf(got), np.isinf(want))
+        fin = np.isfinite(want)
+        np.testing.assert_allclose(got[fin], want[fin], rtol=1e-5, atol=1e-5)
 
 
 def test_config3_properties():
