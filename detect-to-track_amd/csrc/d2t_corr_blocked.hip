@@ -3,20 +3,26 @@
 // d2t_generic.hip (so the results are bit-identical to them, forward and both gradients), with the memory
 // behaviour fixed.  D2T_IMPL_GENERIC keeps the thread-per-element kernels as the correctness anchor; D2T_IMPL_AUTO
 // takes these when the tuned gfx950 kernels do not apply (round 4: the cost of leaving the envelope was 15x forward
-// and 35-150x backward, include/d2t_ops.h).
+// and 35-150x backward, include/d2t_ops.h; now 2.7x / 4x at d_max = 7).
 //
 // Reference semantics: pointwise_correlation_cuda.cu:84-107 (forward), :145-171 (backward).
 //
-//   forward   a thread owns FOUR adjacent cells (ci, cj .. cj+3) of one pixel: per channel one load of FM0[c][i][j] and
-//             one 16-byte (f64: 32-byte) load of FM1[c][di][dj .. dj+3] feed four fused multiply-adds -- the
-//             thread-per-cell kernel issued two loads per multiply-add.  Each cell is still ONE ascending-channel fma
-//             chain (:105-107).  Groups that touch the map's left / right edge take the per-cell path.
-//   backward  the thread-per-element kernel reads gradOut[b][pixel][cell] with the LANES along x, i.e. 4 (2d+1)^2 bytes
-//             apart: one cache line per lane and term.  Here a workgroup stages the cells of (b, row y, XT pixels) in
-//             LDS once and every thread (channel, pixel) walks its window from there; FM is read along x (coalesced).
-//             gradFM1 needs gradOut indexed by the DISPLACED pixel: a pre-pass writes that view into the caller's
-//             workspace (goutT[b][y][x][ci][cj] = gradOut[b][y-ci+d][x-cj+d][ci][cj]), then the same kernel runs with
-//             FM0 and mirrored offsets, centres in ascending (i, j) order as in d2t_generic.hip.
+// f32, d_max <= 14 -- the tiled kernels:
+//   forward   k_corr_fwd_tiled: workgroup = 4 x 8 pixels, the FM1 window and the tile's FM0 pixels in LDS per chunk of 8 / 16
+//             channels (next chunk in flight into registers); thread (pixel column, window row) owns a cell row of four pixels,
+//             one aligned 16-byte LDS read per 16 fused multiply-adds.  Each cell is still ONE ascending-channel fma chain (:105-107).
+//   backward  k_corr_bwd_tiled: thread = four adjacent pixels x four channels; per window row the 2d + 4 values of S its windows
+//             span come as aligned 16-byte loads from zero-padded row copies of the maps (k_corr_pad_rows, workspace); the
+//             (2d+1)^2 gradOut cells of the row's pixels are staged in LDS; columns that do not exist for a pixel are masked out of
+//             the execution.  gradFM1 reads gradOut indexed by the DISPLACED pixel (k_corr_gout_by_displaced, workspace) with FM0
+//             and mirrored offsets, centres in ascending (i, j) order as in d2t_generic.hip.
+// everything else (f64, d_max > 14) -- the blocked kernels:
+//   forward   k_corr_fwd_blocked: a thread owns FOUR adjacent cells (ci, cj .. cj+3) of one pixel: per channel one load of
+//             FM0[c][i][j] and one 16-byte (f64: 32-byte) load of FM1[c][di][dj .. dj+3] feed four fused multiply-adds.  Groups
+//             that touch the map's left / right edge take the per-cell path.  (f64 forward: the thread-per-cell kernel is faster.)
+//   backward  k_corr_bwd_blocked: the thread-per-element kernel reads gradOut[b][pixel][cell] with the LANES along x, i.e.
+//             4 (2d+1)^2 bytes apart: one cache line per lane and term.  Here a workgroup stages the cells of (b, row y, XT pixels)
+//             in LDS once and every thread (channel, pixel) walks its window from there; FM is read along x (coalesced).
 #include "d2t_kernels.hpp"
 
 namespace d2t {

@@ -30,8 +30,8 @@ int psroipool_channels(int32_t* ch, int nT, int k, hipStream_t st);
 int corr_mask(uint8_t* mask, int H, int W, int d, int s, hipStream_t st);
 
 // ---- correlation outside the tuned envelope, reference layout (d2t_corr_blocked.hip): the generic kernels' arithmetic and order
-// (bit-identical results) with four cells per thread (forward) / gradOut staged in LDS (backward; ws = gradOut re-indexed by
-// displaced pixel)
+// (bit-identical results); f32 with d_max <= 14: LDS-tiled forward, register-tiled backward (ws = gradOut re-indexed by displaced
+// pixel | both maps with zero-padded rows); otherwise four cells per thread (forward) / gradOut staged in LDS (backward)
 template <typename T> bool   corr_blocked_supported(int B, int C, int H, int W, int d, int s);
 template <typename T> size_t corr_bwd_blocked_ws_bytes(int B, int C, int H, int W, int d, int s);
 template <typename T> int    corr_fwd_blocked(const T* fm0, const T* fm1, T* out, int B, int C, int H, int W, int d, int s, hipStream_t st);
