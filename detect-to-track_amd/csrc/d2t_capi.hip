@@ -53,7 +53,7 @@ inline size_t bins_bytes(int R, int k) { return align_up((size_t)R * k * k * 4 *
 
 extern "C" {
 
-int d2t_version(void) { return 104; }   // 1.04: round 4 -- D2T_IMPL_FAST / MFMA_WIDE8 / MFMA_STRIP4, d2t_region_filter_batched_f32
+int d2t_version(void) { return 105; }   // 1.05: round 4 -- D2T_IMPL_FAST / MFMA_WIDE8 / MFMA_STRIP4, d2t_region_filter_batched_f32, d2t_corr_bwd_levels_workspace_bytes
 
 const char* d2t_error_string(int code)
 {
@@ -193,10 +193,18 @@ int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* 
     return D2T_OK;
 }
 
+size_t d2t_corr_bwd_levels_workspace_bytes(int n, const int* C, int B, int H, int W, int d, int stride, int layout)
+{
+    if (n < 1 || n > tuned::MAXLV || !C || B < 1 || H < 1 || W < 1 || layout != D2T_LAYOUT_CHANNEL_MAJOR) return 0;
+    for (int l = 0; l < n; ++l)
+        if (!tuned::corr_bwd_supported(B, C[l], H, W, d, stride)) return 0;
+    return tuned::corr_bwd_levels_ws_bytes(n, C, B, H, W, tuned::CellLayout{1, H * W, 0});
+}
+
 int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const* fm0, const float* const* fm1,
                             float* const* gfm0, float* const* gfm1, const int* C,
                             int B, int H, int W, int d, int stride, int layout, long long bstride,
-                            void*, size_t, int impl, d2t_stream_t stream)
+                            void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)gout, C, B, H, W, d, stride, layout, bstride);
@@ -210,7 +218,7 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
     bool tuned_ok = impl != D2T_IMPL_GENERIC;
     for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_bwd_supported(B, C[l], H, W, d, stride);
     if (tuned_ok) return tuned::corr_bwd_levels_f32(n, gout, fm0, fm1, gfm0, gfm1, C, B, H, W, lay, as_stream(stream),
-                                                    bwd_variant_of(impl));
+                                                    bwd_variant_of(impl), ws, ws ? ws_bytes : 0);
     if (demands_tuned(impl)) return D2T_EINVAL;
     for (int l = 0; l < n; ++l) {
         rc = corr_bwd_generic<float>(gout[l], fm0[l], fm1[l], gfm0[l], gfm1[l], B, C[l], H, W, d, stride, as_stream(stream),

@@ -918,19 +918,28 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
     const bool two = 1LL * B * tiles_j * ((tiles_i + 1) / 2) >= 160;   // medium grids: segments of 2 p-tiles
     const int ns = two ? (tiles_i + 1) / 2 : tiles_i;
     const int per_level = B * tiles_j * ns;
-    FwdLevels lv;
-    lv.n = nl;
-    for (int l = 0; l < MAXLV; ++l) {
-        const int src = order[l < nl ? l : nl - 1];
-        lv.fm0[l] = fm0[src]; lv.fm1[l] = fm1[src]; lv.out[l] = out[src]; lv.C[l] = C[src];
-        lv.wg_end[l] = per_level * ((l < nl ? l : nl - 1) + 1);
+    // One launch per level (D2T_EXP_LEVEL_LAUNCHES 0: all levels in one launch).  The tracker's three B = 1 levels are 190 one-tile
+    // workgroups each, one per CU by LDS: three launches 179 us, one 570-workgroup launch 273 us (tools/levels_cost.py) -- the
+    // heavy level's workgroups queue behind the light ones'.
+#ifndef D2T_EXP_LEVEL_LAUNCHES
+#define D2T_EXP_LEVEL_LAUNCHES 1
+#endif
+    const int launches = D2T_EXP_LEVEL_LAUNCHES ? nl : 1, per_launch = D2T_EXP_LEVEL_LAUNCHES ? 1 : nl;
+    for (int q = 0; q < launches; ++q) {
+        FwdLevels lv;
+        lv.n = per_launch;
+        for (int l = 0; l < MAXLV; ++l) {
+            const int src = order[q + (l < per_launch ? l : per_launch - 1)];
+            lv.fm0[l] = fm0[src]; lv.fm1[l] = fm1[src]; lv.out[l] = out[src]; lv.C[l] = C[src];
+            lv.wg_end[l] = per_level * ((l < per_launch ? l : per_launch - 1) + 1);
+        }
+        if (two)
+            hipLaunchKernelGGL((k_corr_fwd_segx<2, 4>), dim3(per_level * per_launch), dim3(SegX<2, 4>::THREADS), 0, st,
+                               lv, H, W, tiles_i, tiles_j, ns, lay);
+        else                                         // small batches (B = 1 pairs): one p-tile per workgroup
+            hipLaunchKernelGGL((k_corr_fwd_segx<1, 4, true>), dim3(per_level * per_launch), dim3(SegX<1, 4, true>::THREADS), 0, st,
+                               lv, H, W, tiles_i, tiles_j, ns, lay);
     }
-    if (two)
-        hipLaunchKernelGGL((k_corr_fwd_segx<2, 4>), dim3(per_level * nl), dim3(SegX<2, 4>::THREADS), 0, st,
-                           lv, H, W, tiles_i, tiles_j, ns, lay);
-    else                                             // small batches (B = 1 pairs): one p-tile per workgroup
-        hipLaunchKernelGGL((k_corr_fwd_segx<1, 4, true>), dim3(per_level * nl), dim3(SegX<1, 4, true>::THREADS), 0, st,
-                           lv, H, W, tiles_i, tiles_j, ns, lay);
     return launch_status();
 }
 
@@ -1422,10 +1431,69 @@ static bool corr_bwd_prefers_wide(int B, int C, int W)
     return D2T_BWD_WIDE_DEFAULT && corr_bwd8w_workgroups(B, C, W) >= 224;
 }
 
+// The channel-major gradient of the tracker's concat buffer, one level: cell c of pixel p of item b at gout[b*bs + c*HW + p].  The
+// 8-wave strip kernels read gradOut in the reference's layout ((2d+1)^2 contiguous cells per pixel); for this layout the levels call
+// first re-lays every level's gradient into the caller's workspace -- 32 x 32 tiles through LDS, ~3 MB per level and item -- and then
+// runs the same kernels as the per-level calls (round 4: the 16-wave kernel that reads the channel-major layout directly took
+// 304 us for the tracker's three B = 1 levels against 195 us for three separate reference-layout calls).
+struct RelayLevels { const float* src[MAXLV]; float* dst[MAXLV]; };
+
+__global__ void __launch_bounds__(256)
+k_corr_relay_cells(RelayLevels lv, int HW, long long bs)
+{
+    __shared__ float tile[32][33];
+    const int L = blockIdx.z, b = blockIdx.y;
+    const float* src = lv.src[0]; float* dst = lv.dst[0];
+#pragma unroll
+    for (int l = 1; l < MAXLV; ++l)
+        if (L == l) { src = lv.src[l]; dst = lv.dst[l]; }
+    src += (size_t)b * bs;
+    dst += (size_t)b * HW * CELLS;
+    constexpr int ctiles = (CELLS + 31) / 32;
+    const int pt = blockIdx.x / ctiles, ct = blockIdx.x - pt * ctiles;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                     // read: cells down, pixels across (contiguous)
+        const int c = ct * 32 + ty + 8 * r, p = pt * 32 + tx;
+        tile[ty + 8 * r][tx] = c < CELLS && p < HW ? src[(size_t)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                     // write: pixels down, cells across (contiguous)
+        const int p = pt * 32 + ty + 8 * r, c = ct * 32 + tx;
+        if (c < CELLS && p < HW) dst[(size_t)p * CELLS + c] = tile[tx][ty + 8 * r];
+    }
+}
+
+size_t corr_bwd_levels_ws_bytes(int nl, const int* C, int B, int H, int W, CellLayout lay)
+{
+    if (lay.cs == 1) return 0;                                        // reference layout: read in place
+    for (int l = 0; l < nl; ++l)
+        if (!corr_bwd8_supported(B, C[l], H, W, CELLS, 1)) return 0;
+    return (size_t)nl * B * H * W * CELLS * sizeof(float);
+}
+
 int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
                         float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
-                        int bwd_variant)
+                        int bwd_variant, void* ws, size_t ws_bytes)
 {
+    const size_t relay = bwd_variant != 1 ? corr_bwd_levels_ws_bytes(nl, C, B, H, W, lay) : 0;
+    if (relay && ws && ws_bytes >= relay) {                           // channel-major gradient: re-lay, then the reference-layout kernels
+        RelayLevels rl;
+        const float* gref[MAXLV];
+        const size_t per = (size_t)B * H * W * CELLS;
+        for (int l = 0; l < MAXLV; ++l) {
+            const int src = l < nl ? l : nl - 1;
+            rl.src[l] = gout[src];
+            rl.dst[l] = static_cast<float*>(ws) + src * per;
+            gref[l] = rl.dst[l];
+        }
+        hipLaunchKernelGGL(k_corr_relay_cells, dim3(((H * W + 31) / 32) * ((CELLS + 31) / 32), B, nl), dim3(256), 0, st, rl, H * W, lay.bs);
+        const int rc = launch_status();
+        if (rc != D2T_OK) return rc;
+        const CellLayout ref{CELLS, 1, 1LL * H * W * CELLS};
+        return corr_bwd_levels_f32(nl, gref, fm0, fm1, g0, g1, C, B, H, W, ref, st, bwd_variant, nullptr, 0);
+    }
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     int small[MAXLV], ns = 0;
     for (int l = 0; l < nl; ++l) {
@@ -1474,7 +1542,7 @@ int corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g
                  int B, int C, int H, int W, int, int, void*, hipStream_t st, int bwd_variant)
 {
     const CellLayout lay{CELLS, 1, 1LL * H * W * CELLS};
-    return corr_bwd_levels_f32(1, &gout, &fm0, &fm1, &g0, &g1, &C, B, H, W, lay, st, bwd_variant);
+    return corr_bwd_levels_f32(1, &gout, &fm0, &fm1, &g0, &g1, &C, B, H, W, lay, st, bwd_variant, nullptr, 0);
 }
 
 }}  // namespace d2t::tuned

@@ -22,7 +22,8 @@ int    corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* 
                            int B, int H, int W, CellLayout lay, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 int    corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
                            float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
-                           int bwd_variant = 0);
+                           int bwd_variant = 0, void* ws = nullptr, size_t ws_bytes = 0);
+size_t corr_bwd_levels_ws_bytes(int nl, const int* C, int B, int H, int W, CellLayout lay);   // channel-major gradient: its re-laid copy
 
 bool   corr_bwd_supported(int B, int C, int H, int W, int d, int s);
 size_t corr_bwd_ws_bytes(int B, int C, int H, int W, int d, int s);

@@ -203,9 +203,10 @@ def pointwise_correlation_levels_backward(grad, c0: int, FM0s, FM1s, d_max: int,
         g1 = [torch.empty_like(b) for b in FM1s]
         gouts = [grad[:, c0 + l * cells: c0 + (l + 1) * cells] for l in range(L)]
         Cs = (ctypes.c_int * L)(*[int(a.shape[1]) for a in FM0s])
+        ws, n = _workspace(_native.lib.d2t_corr_bwd_levels_workspace_bytes(L, Cs, B, H, W, d_max, stride, _native.LAYOUT_CHANNEL_MAJOR), grad)
         rc = _native.lib.d2t_corr_bwd_levels_f32(
             L, _ptr_array(gouts), _ptr_array(FM0s), _ptr_array(FM1s), _ptr_array(g0), _ptr_array(g1), Cs,
-            B, H, W, d_max, stride, _native.LAYOUT_CHANNEL_MAJOR, grad.shape[1] * H * W, 0, 0, impl, _stream(grad))
+            B, H, W, d_max, stride, _native.LAYOUT_CHANNEL_MAJOR, grad.shape[1] * H * W, _ptr(ws), n, impl, _stream(grad))
     _native.check(rc, "pointwise_correlation_levels_backward")
     return g0, g1
 

@@ -79,7 +79,9 @@ _proto("d2t_corr_fwd_levels_f32", _I, [_I, _P, _P, _P, _P] + [_I] * 5 + [_I, cty
 _proto("d2t_corr_bwd_levels_f32", _I, [_I, _P, _P, _P, _P, _P, _P] + [_I] * 5 + [_I, ctypes.c_longlong, _P, _Z, _I, _P])
 # (n, C[], B,H,W,d,stride)
 _proto("d2t_corr_fwd_levels_workspace_bytes", _Z, [_I, _P] + [_I] * 5)
-SYMBOLS += ["d2t_corr_fwd_levels_f32", "d2t_corr_bwd_levels_f32", "d2t_corr_fwd_levels_workspace_bytes"]
+_proto("d2t_corr_bwd_levels_workspace_bytes", _Z, [_I, _P] + [_I] * 6)
+SYMBOLS += ["d2t_corr_fwd_levels_f32", "d2t_corr_bwd_levels_f32", "d2t_corr_fwd_levels_workspace_bytes",
+            "d2t_corr_bwd_levels_workspace_bytes"]
 LAYOUT_REFERENCE, LAYOUT_CHANNEL_MAJOR = 0, 1
 # (A, max_dets) ; (anchors, offsets, confs, A, conf_thresh, max_dets, iou_thresh, out_boxes, out_conf, out_idx, out_count, ws, ws_bytes, stream)
 _proto("d2t_region_filter_workspace_bytes", _Z, [_I, _I])

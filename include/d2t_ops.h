@@ -133,7 +133,7 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1,
  * with three calls, turns each (1,H,W,2d+1,2d+1) result into ((2d+1)^2,H,W) with view + permute, and
  * torch.cat's them behind the two RPN feature maps before ROIPool.  These entry points run
  * n_levels <= 4 correlations that share (B,H,W,d,stride) -- level l has C[l] channels -- in one
- * call (one launch where the grids are small), and can write / read the output in the layout the
+ * call, and can write / read the output in the layout the
  * concatenation needs:
  *   D2T_LAYOUT_REFERENCE      out[l] is (B,H,W,2d+1,2d+1), batch_stride ignored
  *   D2T_LAYOUT_CHANNEL_MAJOR  cell (ci,cj) of pixel (i,j) of item b at
@@ -155,6 +155,12 @@ int d2t_corr_fwd_levels_f32(int n_levels, const float* const* fm0, const float* 
                             const int* C, int B, int H, int W, int d, int stride,
                             int layout, long long batch_stride,
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
+/* Scratch of the backward levels call for D2T_LAYOUT_CHANNEL_MAJOR: with it the gradient is first re-laid into the reference's
+ * layout and the kernels of d2t_corr_bwd_f32 run on that copy (the tracker's three B = 1 levels: 205 us instead of 304 us with the
+ * kernel that reads the channel-major layout in place -- which still runs when ws is NULL / too small; same 1e-5 contract).
+ * 0 for the reference layout and for shapes outside the tuned envelope. */
+size_t d2t_corr_bwd_levels_workspace_bytes(int n_levels, const int* C, int B, int H, int W, int d, int stride, int layout);
+
 int d2t_corr_bwd_levels_f32(int n_levels, const float* const* gout, const float* const* fm0, const float* const* fm1,
                             float* const* gfm0, float* const* gfm1,
                             const int* C, int B, int H, int W, int d, int stride,

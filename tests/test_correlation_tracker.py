@@ -76,15 +76,10 @@ def test_levels_forward_backward_equal_unfused(case):
     for l, (a, b) in enumerate(zip(fm0s, fm1s)):
         gl = gbuf[:, pad0 + l * cells: pad0 + (l + 1) * cells].permute(0, 2, 3, 1).reshape(B, H, W, 2 * d + 1, 2 * d + 1)
         r0, r1 = _ext.pointwise_correlation_backward(gl.contiguous(), a, b, d, s)
-        # Same terms either way; bit-equal where both calls run the same kernel.  With d = 8, stride 1 and a map of at least
-        # 17 x 20 the reference-layout call takes the 8-wave strip kernel (d2t_corr_bwd8.hip) and the channel-major call
-        # the 16- / 4-wave ones, which enumerate a tile's window slots in a different order: 1e-5 of the gradient's
-        # scale (both are held to the oracle in test_levels_backward_matches_oracle / test_matches_oracle).
-        if d == 8 and s == 1 and H >= 17 and W >= 20:
-            for x, y in ((g0[l], r0), (g1[l], r1)):
-                torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-5 * float(y.abs().max()))
-        else:
-            assert torch.equal(g0[l], r0) and torch.equal(g1[l], r1)
+        # Same kernels either way: where the reference-layout call takes the 8-wave strip kernel (d = 8, stride 1, a map of at
+        # least 17 x 20) the channel-major call first re-lays the gradient into the workspace d2t_corr_bwd_levels_workspace_bytes
+        # asks for and runs that kernel on the copy; elsewhere both run the 16- / 4-wave kernels -- bit-equal in every case.
+        assert torch.equal(g0[l], r0) and torch.equal(g1[l], r1)
 
 
 def test_levels_match_oracle(oracle):
