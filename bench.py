@@ -180,16 +180,24 @@ class HipDevice:
     launch stream, RCCL process group.  (`torch.distributed` backend "nccl" is RCCL on ROCm.)"""
     backend = "nccl"
 
-    def __init__(self, local_rank, impl):
+    def __init__(self, local_rank, impl, backend="nccl"):
         import torch
         from detect_to_track.models import _native       # raises ImportError if the HIP library is missing
-        self.torch, self.native, self.lib, self.impl = torch, _native, _native.lib, impl
+        self.torch, self.native, self.lib, self.impl, self.backend = torch, _native, _native.lib, impl, backend
+        if backend != "nccl":                            # rehearsal (--backend gloo): the ranks may share a GPU
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
 
+    def gpus_visible(self):
+        return self.torch.cuda.device_count()
+
     def init_process_group(self):
         import torch.distributed as dist
-        dist.init_process_group(self.backend, device_id=self.dev)
+        if self.backend == "nccl":
+            dist.init_process_group("nccl", device_id=self.dev)
+        else:
+            dist.init_process_group(self.backend)
 
     def setup(self, cfg, n_sets, seed):
         torch = self.torch
@@ -502,6 +510,7 @@ def run(args, device):
             "pct_hbm_roofline_bwd": 100 * kernels[1]["hbm"]["frac"],
             "settle_steps": settle_steps, "settle_ms": settle_ms, "ranks_seen": ranks_seen,
             "process_group": getattr(device, "backend", None) if dist_on else None,
+            "gpus_visible": device.gpus_visible() if hasattr(device, "gpus_visible") else None,    # < n_gpus: a rehearsal, ranks share GPUs
             "event_pass": {"ms_per_step": ms_ev, "records_per_step": 2, "event_record_overhead_us": record_us,
                            "host_ms_per_step_minus_device": ms_ev - t_dev},
             "graph_replay": graph_replay,
@@ -536,6 +545,8 @@ def parse_args(argv=None):
     ap.add_argument("--ops", type=int, default=1, help="1: also time every other op / shape of the path (ops[] in the line, rank 0, ~3 s)")
     ap.add_argument("--force-dist", type=int, default=0, help="1: create the process group and run the collectives at world size 1 too "
                     "(launch under torch.distributed.run --nproc-per-node 1)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend: nccl = RCCL, one GPU per rank (the metric); gloo lets several "
+                    "ranks REHEARSE the N > 1 path on one GPU (they share it: the line says so, its value is not a scaling figure)")
     ap.add_argument("--settle-ms", type=float, default=SETTLE_MS, help="untimed steps until this much wall time has passed (clock settling)")
     return ap.parse_args(argv)
 
@@ -548,7 +559,7 @@ def main(argv=None, device_factory=None, script=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(script or Path(__file__).resolve(), argv, args.gpus))
-    device = device_factory() if device_factory else HipDevice(rank_env()[2], args.impl)
+    device = device_factory() if device_factory else HipDevice(rank_env()[2], args.impl, args.backend)
     return run(args, device)
 
 
