@@ -3,9 +3,13 @@
 // These are the correctness anchors of the library: one thread owns one output element
 // and accumulates it in the reference's own order wherever the reference defines one, so
 // forward results are bit-identical to a serial evaluation of the reference arithmetic
-// (FMA-contracted as nvcc builds it).  They serve every case the tuned gfx950 kernels
-// do not take (f64, correlation stride > 1, odd shapes).  All backward kernels are in
-// gather form: no atomics, every output element written exactly once, deterministic.
+// (FMA-contracted as nvcc builds it).  D2T_IMPL_GENERIC selects them; under the default
+// dispatch they serve what neither the tuned gfx950 kernels nor the second tier
+// (d2t_corr_blocked.hip, d2t_pool_lists.hip: the same operations in the same order, bit-identical
+// results, without the per-thread redundancy) take: maps narrower than 4 columns, d_max whose
+// window does not fit LDS, fewer than 32 RoIs in the ROIPool forward, callers that pass no
+// workspace.  All backward kernels are in gather form: no atomics, every output element written
+// exactly once, deterministic.
 //
 // Reference semantics (paths relative to /root/reference/detect_to_track/models/):
 //   correlation  pointwise_correlation/pointwise_correlation_cuda.cu:62-174
