@@ -915,7 +915,8 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
     for (int a = 0; a < nl; ++a)                     // heaviest first (nl <= 4)
         for (int b2 = a + 1; b2 < nl; ++b2)
             if (C[order[b2]] > C[order[a]]) { const int t = order[a]; order[a] = order[b2]; order[b2] = t; }
-    const bool two = 1LL * B * tiles_j * ((tiles_i + 1) / 2) >= 160;   // medium grids: segments of 2 p-tiles
+    const bool two = 1LL * B * tiles_j * ((tiles_i + 1) / 2) >= 160;   // medium grids: segments of 2 p-tiles (B = 2, 38 x 63 / 75, C = 2048:
+                                                                        // 160 us against 181 us with one-tile workgroups, tools/levels_cost.py)
     const int ns = two ? (tiles_i + 1) / 2 : tiles_i;
     const int per_level = B * tiles_j * ns;
     // One launch per level (D2T_EXP_LEVEL_LAUNCHES 0: all levels in one launch).  The tracker's three B = 1 levels are 190 one-tile

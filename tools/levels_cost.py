@@ -11,7 +11,8 @@ from bench_ops import timed  # noqa: E402
 dev = "cuda:0"
 H, W, Cs = 38, 75, (512, 1024, 2048)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-print("B =", B)
+W = int(sys.argv[2]) if len(sys.argv) > 2 else W
+print("B =", B, "W =", W, flush=True)
 f0 = [torch.rand(B, C, H, W, device=dev) for C in Cs]
 f1 = [torch.rand(B, C, H, W, device=dev) for C in Cs]
 g = torch.rand(B, len(Cs) * 289, H, W, device=dev)
