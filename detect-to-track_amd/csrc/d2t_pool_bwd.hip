@@ -371,7 +371,15 @@ k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, in
 }
 
 constexpr int RG_CH = 128;                    // k-steps (of 4 slots) per LDS chunk of the list: 8 KB
-constexpr int RG_PF = 4;                      // k-steps of gradOut loads in flight per wave
+// lab overrides (make EXTRA=-D...), round 4 at config 3: 8 pairs in flight 67.1 us, 8 waves per task 72.2 us, both 72.5 us against
+// 65.7 us for (4, 4) -- the kernel is bound by the instructions of a k-step (list entry, scale, indicator), not by its loads' latency
+#ifndef D2T_RG_PF
+#define D2T_RG_PF 4
+#endif
+#ifndef D2T_ROI_NW
+#define D2T_ROI_NW 4
+#endif
+constexpr int RG_PF = D2T_RG_PF;              // pairs (two k-steps) of gradOut loads in flight per wave
 
 // NCT: c-tiles (16 channels) per task, NW: waves that split a task's slots.  (NCT, NW) at config 3, whole op:
 // (1,4) 158 us, (2,4) 91 us, (4,4) 97 us, (2,2) 128 us -- fewer channels per task repeat the per-k-step
@@ -538,7 +546,7 @@ static int roipool_bwd_mfma_f32(const float* gout, const float* rois, float* gin
                            C, H, W, cap, ncb, ntasks, (unsigned)((size_t)R * C * KK * sizeof(float)));                 \
     }
 #define D2T_LAUNCH_GEMM_X(NCTV, NWV) { if (xt <= 4) D2T_LAUNCH_GEMM(4, NCTV, NWV) else if (xt <= 5) D2T_LAUNCH_GEMM(5, NCTV, NWV) else D2T_LAUNCH_GEMM(8, NCTV, NWV) }
-    if (cfg == 1) D2T_LAUNCH_GEMM_X(1, 4) else if (cfg == 2) D2T_LAUNCH_GEMM_X(2, 4) else if (cfg == 3) D2T_LAUNCH_GEMM_X(4, 4) else D2T_LAUNCH_GEMM_X(2, 2)
+    if (cfg == 1) D2T_LAUNCH_GEMM_X(1, 4) else if (cfg == 2) D2T_LAUNCH_GEMM_X(2, D2T_ROI_NW) else if (cfg == 3) D2T_LAUNCH_GEMM_X(4, 4) else D2T_LAUNCH_GEMM_X(2, 2)
 #undef D2T_LAUNCH_GEMM_X
 #undef D2T_LAUNCH_GEMM
     return launch_status();
