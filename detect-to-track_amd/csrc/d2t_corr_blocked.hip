@@ -12,9 +12,9 @@
 //             channels (next chunk in flight into registers); thread (pixel column, window row) owns a cell row of four pixels,
 //             one aligned 16-byte LDS read per 16 fused multiply-adds.  Each cell is still ONE ascending-channel fma chain (:105-107).
 //   backward  k_corr_bwd_tiled: thread = four adjacent pixels x four channels; per window row the 2d + 4 values of S its windows
-//             span come as aligned 16-byte loads from zero-padded row copies of the maps (k_corr_pad_rows, workspace); the
+//             span come as aligned 16-byte loads from zero-padded row copies of the maps (k_corr_bwd_prepass, workspace); the
 //             (2d+1)^2 gradOut cells of the row's pixels are staged in LDS; columns that do not exist for a pixel are masked out of
-//             the execution.  gradFM1 reads gradOut indexed by the DISPLACED pixel (k_corr_gout_by_displaced, workspace) with FM0
+//             the execution (stride 1: no masks at all, see S1).  gradFM1 reads gradOut indexed by the DISPLACED pixel (workspace) with FM0
 //             and mirrored offsets, centres in ascending (i, j) order as in d2t_generic.hip.
 // everything else (f64, d_max > 14) -- the blocked kernels:
 //   forward   k_corr_fwd_blocked: a thread owns FOUR adjacent cells (ci, cj .. cj+3) of one pixel: per channel one load of
@@ -278,33 +278,55 @@ k_corr_bwd_blocked(const T* __restrict__ G, const T* __restrict__ S, T* __restri
 }
 
 
-// A feature map with d zero columns before and >= d + 6 after every row (row pitch Wp, a multiple of 4): what the register-tiled
-// backward reads its 16-byte pieces from -- every piece is aligned and inside the row, no edge cases.
+// Pre-passes of the tiled backward, ONE launch (blockIdx.y: 0 / 1 = FM0 / FM1 copied with d zero columns before and >= d + 6 after every row,
+// row pitch Wp a multiple of 4 -- every 16-byte piece the kernel reads is aligned and inside a row, no edge cases; 2 = gradOut re-indexed by
+// displaced pixel, see k_corr_gout_by_displaced).
 __global__ void __launch_bounds__(kBlk)
-k_corr_pad_rows(const float* __restrict__ S, float* __restrict__ P, long long rows, int W, int Wp, int d)
+k_corr_bwd_prepass(const float* __restrict__ fm0, const float* __restrict__ fm1, const float* __restrict__ gout,
+                   float* __restrict__ pad0, float* __restrict__ pad1, float* __restrict__ goutT,
+                   long long rows, int B, int H, int W, int Wp, int d)
 {
-    const long long total = rows * Wp;
+    if (blockIdx.y < 2) {
+        const float* S = blockIdx.y ? fm1 : fm0;
+        float* P = blockIdx.y ? pad1 : pad0;
+        const long long total = rows * Wp;
+        for (long long i64 = (long long)blockIdx.x * kBlk + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlk) {
+            const long long row = i64 / Wp;
+            const int col = (int)(i64 - row * Wp) - d;
+            P[i64] = (col >= 0 && col < W) ? S[row * W + col] : 0.f;
+        }
+        return;
+    }
+    const int cw = 2 * d + 1, cells = cw * cw, plane = H * W;
+    const long long total = 1LL * B * plane * cells;
     for (long long i64 = (long long)blockIdx.x * kBlk + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlk) {
-        const long long row = i64 / Wp;
-        const int col = (int)(i64 - row * Wp) - d;
-        P[i64] = (col >= 0 && col < W) ? S[row * W + col] : 0.f;
+        const int cell = (int)(i64 % cells);
+        const int pix = (int)(i64 / cells);
+        const int cj = cell % cw, ci = cell / cw;
+        const int x = pix % W, y = (pix / W) % H, b = pix / plane;
+        const int i = y - ci + d, j = x - cj + d;
+        goutT[i64] = (i >= 0 && i < H && j >= 0 && j < W) ? gout[((size_t)(b * plane + i * W + j)) * cells + cell] : 0.f;
     }
 }
 
 // One gradient, f32, register-tiled (d <= 14).  Same sums in the same order as k_corr_bwd_blocked -- thread-owned, rows then columns
 // ascending -- but a thread owns FOUR adjacent pixels of the row and CT channels: per window row it loads, per channel, the
-// 4 NQ >= 2d + 4 values of S its four windows span with aligned 16-byte loads (S comes with zero-padded rows, k_corr_pad_rows), and every gradOut cell it reads from LDS feeds CT fused
+// 4 NQ >= 2d + 4 values of S its four windows span with aligned 16-byte loads (S comes with zero-padded rows, k_corr_bwd_prepass), and every gradOut cell it reads from LDS feeds CT fused
 // multiply-adds.  (k_corr_bwd_blocked issues one LDS read and one 4-byte global load per multiply-add.)  Which columns k of the
 // window exist for pixel px (map edge, stride, the never-visited last column) does not depend on the row or the channel: one bit
 // mask per pixel, and a term whose bit is clear is not executed at all -- non-finite values outside the window cannot leak in.
-template <bool MIRROR, int NQ, int CT>
+// S1 (stride 1): the only column inside the map that does not belong to a pixel's sum is the same for every pixel (the last one, 2d --
+// MIRROR: the first), so it is skipped by a wave-uniform test; columns outside the map meet S = 0 from the padded copy and a gradOut
+// cell that is zeroed while it is staged (MIRROR: by k_corr_gout_by_displaced), and fma(0, 0, acc) = acc exactly (acc, started at +0,
+// is never -0).  No masks, no selects: the multiply-adds are unconditional.
+template <bool MIRROR, int NQ, int CT, bool S1>
 __global__ void __launch_bounds__(kBlk)
 k_corr_bwd_tiled(const float* __restrict__ G, const float* __restrict__ S, float* __restrict__ gx,
                  int B, int C, int H, int W, int Wp, int d, int s, int XT, int CB)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef float f4v __attribute__((ext_vector_type(4)));
-    float* gl = reinterpret_cast<float*>(lds_raw);                    // [XT][cells]
+    float* gl = reinterpret_cast<float*>(lds_raw) + 4;                // [XT][cells], four floats of padding either side
     const int cw = 2 * d + 1, cells = cw * cw, plane = H * W;
     const int xtiles = (W + XT - 1) / XT, cblocks = (C + CB - 1) / CB;
     int t = blockIdx.x;
@@ -314,6 +336,16 @@ k_corr_bwd_tiled(const float* __restrict__ G, const float* __restrict__ S, float
     const int xb = xt * XT, nx = W - xb < XT ? W - xb : XT;
     const float* gsrc = G + ((size_t)(b * plane + y * W + xb)) * cells;   // nx * cells contiguous elements
     for (int e = threadIdx.x; e < nx * cells; e += kBlk) gl[e] = gsrc[e];
+    if (S1 && !MIRROR && (xb < d || xb + nx + d > W)) {               // cells whose displaced column lies outside the map: never read by
+        __syncthreads();                                              //  the reference, zeroed here (see S1 above); edge workgroups only
+        for (int e = threadIdx.x; e < nx * cw; e += kBlk) {           // (pixel, cell row): columns [0, klo) and [khi, cw)
+            const int px = e / cw, x = xb + px;
+            const int klo = d - x > 0 ? d - x : 0, khi = W + d - x < cw ? W + d - x : cw;
+            float* rowp = gl + (size_t)px * cells + (e - px * cw) * cw;
+            for (int k = 0; k < klo; ++k) rowp[k] = 0.f;
+            for (int k = khi; k < cw; ++k) rowp[k] = 0.f;
+        }
+    }
     __syncthreads();
     const int nxg = XT >> 2, xg = threadIdx.x % nxg, cl = threadIdx.x / nxg, nch = kBlk / nxg;
     const int x0 = xb + 4 * xg;
@@ -362,15 +394,38 @@ k_corr_bwd_tiled(const float* __restrict__ G, const float* __restrict__ S, float
                 }
             }
             const float* gr = glx + rc * cw + (MIRROR ? 2 * d : 0);   // cell (rc, k) -- MIRROR: (rc, 2d - k)
+            // The cells of column k + 1 are read (unconditionally: the image is padded) while the masked multiply-adds of column k
+            // issue; sched_barrier keeps hipcc from hoisting ALL the reads to the top of the row (237 VGPRs, two waves per SIMD) or
+            // sinking each into its masked block (an exposed LDS round trip per term).  With the reads out of the way hipcc turns the
+            // masked blocks into unconditional multiply-adds + selects on row-invariant lane masks.  (A wave-uniform fast path for
+            // columns every lane has -- a branch per term -- measured 404 against 268 us: the branches end the scheduling regions.)
+            float gv[2][4];
 #pragma unroll
-            for (int k = 0; k < 4 * NQ - 3; ++k)                      // columns ascending
+            for (int px = 0; px < 4; ++px) gv[0][px] = gr[px * cells];
 #pragma unroll
-                for (int px = 0; px < 4; ++px)
-                    if ((mask[px] >> k) & 1u) {
-                        const float gv = gr[px * cells + (MIRROR ? -k : k)];
+            for (int k = 0; k < 4 * NQ - 3; ++k) {                    // columns ascending
+                if (k + 1 < 4 * NQ - 3) {
 #pragma unroll
-                        for (int ch = 0; ch < CT; ++ch) acc[ch][px] = fma_t(gv, seg[ch][k + px], acc[ch][px]);
+                    for (int px = 0; px < 4; ++px) gv[(k + 1) & 1][px] = gr[px * cells + (MIRROR ? -(k + 1) : k + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (S1) {
+                    if (k < cw && k != (MIRROR ? 0 : 2 * d)) {        // wave-uniform
+#pragma unroll
+                        for (int px = 0; px < 4; ++px)
+#pragma unroll
+                            for (int ch = 0; ch < CT; ++ch) acc[ch][px] = fma_t(gv[k & 1][px], seg[ch][k + px], acc[ch][px]);
                     }
+                } else {
+#pragma unroll
+                    for (int px = 0; px < 4; ++px)
+                        if ((mask[px] >> k) & 1u) {
+#pragma unroll
+                            for (int ch = 0; ch < CT; ++ch) acc[ch][px] = fma_t(gv[k & 1][px], seg[ch][k + px], acc[ch][px]);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int ch = 0; ch < CT; ++ch)
@@ -453,26 +508,27 @@ static int corr_bwd_tiled_f32(const float* gout, const float* fm0, const float* 
     const long long rows = 1LL * B * C * H;
     float* pad0 = goutT + ((size_t)B * H * W * cells + 63) / 64 * 64;     // workspace: gradOut by displaced pixel | FM0 padded | FM1 padded
     float* pad1 = pad0 + (size_t)rows * Wp;
-    hipLaunchKernelGGL(k_corr_pad_rows, dim3(grid_for(rows * Wp, kBlk, 256 * 32)), dim3(kBlk), 0, st, fm0, pad0, rows, W, Wp, d);
-    hipLaunchKernelGGL(k_corr_pad_rows, dim3(grid_for(rows * Wp, kBlk, 256 * 32)), dim3(kBlk), 0, st, fm1, pad1, rows, W, Wp, d);
+    {
+        const long long most = rows * Wp > 1LL * B * H * W * cells ? rows * Wp : 1LL * B * H * W * cells;
+        hipLaunchKernelGGL(k_corr_bwd_prepass, dim3(grid_for(most, kBlk, 256 * 16), 3), dim3(kBlk), 0, st, fm0, fm1, gout, pad0, pad1, goutT,
+                           rows, B, H, W, Wp, d);
+    }
     const int nq = (int)(cw + 3 + 3) / 4;                             // 16-byte pieces spanning the four windows of a thread: 1 .. 8
     const int CB = (kBlk / (XT / 4)) * CT < 64 ? 64 : (kBlk / (XT / 4)) * CT;   // one channel pass per workgroup where C allows
-    const size_t lds = (size_t)XT * cells * sizeof(float);
+    const size_t lds = ((size_t)XT * cells + 8) * sizeof(float);
     const int grid = B * H * ((W + XT - 1) / XT) * ((C + CB - 1) / CB);
     int rc = D2T_OK;
     for (int pass = 0; pass < 2 && rc == D2T_OK; ++pass) {
         const float* G = pass ? goutT : gout;
         const float* S = pass ? pad0 : pad1;
         float* gx = pass ? g1 : g0;
-        if (pass) {
-            hipLaunchKernelGGL(k_corr_gout_by_displaced<float>, dim3(grid_for(1LL * B * H * W * cells, kBlk, 256 * 32)), dim3(kBlk), 0, st, gout, goutT, B, H, W, d);
-            if ((rc = launch_status()) != D2T_OK) break;
-        }
         switch (nq) {
-#define D2T_TILED(N) case N: if (pass) hipLaunchKernelGGL((k_corr_bwd_tiled<true, N, CT>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, Wp, d, s, XT, CB); \
-                             else hipLaunchKernelGGL((k_corr_bwd_tiled<false, N, CT>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, Wp, d, s, XT, CB); break;
+#define D2T_TILED_S(N, M, U) hipLaunchKernelGGL((k_corr_bwd_tiled<M, N, CT, U>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, Wp, d, s, XT, CB)
+#define D2T_TILED(N) case N: if (pass) { if (s == 1) D2T_TILED_S(N, true, true); else D2T_TILED_S(N, true, false); } \
+                             else { if (s == 1) D2T_TILED_S(N, false, true); else D2T_TILED_S(N, false, false); } break;
             D2T_TILED(1) D2T_TILED(2) D2T_TILED(3) D2T_TILED(4) D2T_TILED(5) D2T_TILED(6) D2T_TILED(7) D2T_TILED(8)
 #undef D2T_TILED
+#undef D2T_TILED_S
             default: return D2T_EINVAL;
         }
         rc = launch_status();
