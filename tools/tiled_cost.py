@@ -11,7 +11,8 @@ from detect_to_track.models import _ext  # noqa: E402
 from bench_ops import timed  # noqa: E402
 warnings.simplefilter("ignore")
 dev = "cuda:0"
-shapes = [(8, 256, 38, 63, 7, 1), (1, 256, 38, 63, 7, 1), (8, 256, 38, 63, 4, 1), (8, 256, 38, 63, 12, 1), (8, 256, 38, 63, 8, 2)]
+shapes = [(8, 256, 38, 63, 7, 1), (1, 256, 38, 63, 7, 1), (8, 256, 38, 63, 4, 1), (8, 256, 38, 63, 12, 1), (8, 256, 38, 63, 8, 2),
+          (8, 256, 38, 63, 2, 1), (8, 256, 38, 63, 5, 1), (8, 256, 38, 63, 6, 1), (2, 1024, 38, 63, 6, 1)]
 if len(sys.argv) > 1:
     shapes = shapes[:int(sys.argv[1])]
 for (B, C, H, W, d, s) in shapes:
