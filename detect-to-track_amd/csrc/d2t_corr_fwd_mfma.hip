@@ -4,8 +4,9 @@
 // (pointwise_correlation_cuda.cu:105-107; d2t_corr_tuned.hip states and tests the same for d_max = 8), successive MFMAs continue that
 // chain in ascending channel order, and the zero channels that pad C to a multiple of 4 add fma(0, 0, acc) = acc exactly.
 //
-// Workgroup = 4 x 16 pixels = four 4 x 4 pixel tiles side by side, one wave each (two from d_max 3 up: they split the N-tiles).  Per chunk of 8 channels the union of their windows
-// ((4 + 2d) rows x (16 + 2d) columns of FM1, zero outside the map) and the 64 pixels of FM0 are staged in LDS (the next chunk is in
+// Workgroup = 4 x 16 (or 4 x 8) pixels = four (two) 4 x 4 pixel tiles side by side, one wave each (two from d_max 3 up: they split the
+// N-tiles).  Per chunk of 8 channels the union of their windows
+// ((4 + 2d) rows x (16 + 2d) columns of FM1, zero outside the map) and the workgroup's pixels of FM0 are staged in LDS (the next chunk is in
 // flight into registers meanwhile).  A wave multiplies its tile's 16 pixels (M) with ALL the positions of its tile's window, 16 at a
 // time (N-tiles: the (4 + 2d) x WCL window, row-major with rows padded to a multiple of 4), 4 channels per MFMA (K): one LDS read
 // per operand and MFMA.  Of the 16 x 16 products of an MFMA those whose position lies inside the pixel's own (2d + 1)^2 window are
@@ -25,7 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKC = 8;                                               // channels per staged chunk (two MFMA k-steps; 16: 114 against 118 us at
                                                                      // d_max 7 for 60 more registers -- not taken)
 
-template <int D>
+template <int D, int TP>                                          // TP: 4 x 4 p-tiles side by side per workgroup (4 or 2)
 struct FwdMfma {
     static constexpr int CW = 2 * D + 1, CELLS = CW * CW;
     static constexpr int WR = 4 + 2 * D;                            // window rows
@@ -33,34 +34,35 @@ struct FwdMfma {
     static constexpr int NT = (WR * WCL + 15) / 16;                 // N-tiles of a tile's window
     static constexpr int WPT = NT >= 8 ? 2 : 1;                     // waves per tile: they split the N-tiles (accumulators + operand offsets
     static constexpr int NTW = (NT + WPT - 1) / WPT;                //  of 23-25 N-tiles leave one wave per SIMD: 172 + 88 registers at d_max 7)
-    static constexpr int THREADS = 256 * WPT;
-    static constexpr int WCP = (16 + 2 * D + 3) & ~3;               // the workgroup's window columns, padded
+    static constexpr int PX = 16 * TP;                             // pixels per workgroup
+    static constexpr int THREADS = 64 * TP * WPT;
+    static constexpr int WCP = (4 * TP + 2 * D + 3) & ~3;           // the workgroup's window columns, padded
     static constexpr int WIMG = WR * WCP;
-    static constexpr int CST = ((WIMG + 64 + 15) & ~15) + 16;       // floats per staged channel (+16: the four channels of a k-step on different banks)
+    static constexpr int CST = ((WIMG + PX + 15) & ~15) + 16;       // floats per staged channel (+16: the four channels of a k-step on different banks)
     static constexpr int NPOS = (WIMG + THREADS - 1) / THREADS;     // window elements per thread and channel
     static constexpr size_t LDS_LOOP = (size_t)kKC * CST * sizeof(float);
-    static constexpr size_t LDS_EPI = (size_t)64 * CELLS * sizeof(float);
+    static constexpr size_t LDS_EPI = (size_t)PX * CELLS * sizeof(float);
     static constexpr size_t LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
 };
 
-template <int D>
-__global__ void __launch_bounds__(FwdMfma<D>::THREADS)
+template <int D, int TP>
+__global__ void __launch_bounds__((FwdMfma<D, TP>::THREADS))
 k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
                 int B, int C, int H, int W, int s)
 {
-    using P = FwdMfma<D>;
-    constexpr int kThreads = P::THREADS;
+    using P = FwdMfma<D, TP>;
+    constexpr int kThreads = P::THREADS, TW = 4 * TP;                // TW: pixel columns of the workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* img = reinterpret_cast<float*>(lds_raw);
     const int plane = H * W;
-    const int tiles_j = (W + 15) / 16, tiles_i = (H + 3) / 4;
+    const int tiles_j = (W + TW - 1) / TW, tiles_i = (H + 3) / 4;
     int tb = blockIdx.x;
     const int tj = tb % tiles_j; tb /= tiles_j;
     const int ti = tb % tiles_i, b = tb / tiles_i;
-    const int i0 = 4 * ti, j0 = 16 * tj;
+    const int i0 = 4 * ti, j0 = TW * tj;
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t = wv & 3, nt0 = (wv >> 2) * P::NTW;                  // this wave's tile and its first N-tile
+    const int t = wv % TP, nt0 = (wv / TP) * P::NTW;                 // this wave's tile and its first N-tile
     const float* f0b = fm0 + (size_t)b * C * plane;
     const float* f1b = fm1 + (size_t)b * C * plane;
 
@@ -73,11 +75,11 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
         dst_off[e] = pos < P::WIMG ? pos : -1;
         src_off[e] = (pos < P::WIMG && gi >= 0 && gi < H && gj >= 0 && gj < W) ? gi * W + gj : -1;
     }
-    const int px = tid & 63, pxi = px >> 4, pxj = px & 15;             // pixel (pxi, pxj) of the 4 x 16 block; stored [tile][4 * pi + pj]
+    const int px = tid % P::PX, pxi = px / TW, pxj = px - pxi * TW;    // pixel (pxi, pxj) of the 4 x TW block; stored [tile][4 * pi + pj]
     const int src0 = (i0 + pxi < H && j0 + pxj < W) ? (i0 + pxi) * W + j0 + pxj : -1;
     const int dst0 = P::WIMG + (pxj >> 2) * 16 + 4 * pxi + (pxj & 3);
-    const int k0 = tid >> 6;                                           // channels k0 (and, four waves: k0 + 4) of the chunk
-    constexpr int NP0 = kKC * 64 / kThreads;                           // 2 or 1
+    const int k0 = tid / P::PX;                                        // channels k0, k0 + KS, ... of the chunk
+    constexpr int KS = kThreads / P::PX, NP0 = kKC / KS;               // (KS = 4 or 8 with one / two waves per tile)
 
     float pre[P::NPOS][kKC], pre0[NP0];
     auto fetch = [&](int c0) {
@@ -88,7 +90,7 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
                 pre[e][k] = (src_off[e] >= 0 && c0 + k < C) ? f1b[(size_t)(c0 + k) * plane + src_off[e]] : 0.f;
 #pragma unroll
         for (int h = 0; h < NP0; ++h)
-            pre0[h] = (src0 >= 0 && c0 + k0 + 4 * h < C) ? f0b[(size_t)(c0 + k0 + 4 * h) * plane + src0] : 0.f;
+            pre0[h] = (src0 >= 0 && c0 + k0 + KS * h < C) ? f0b[(size_t)(c0 + k0 + KS * h) * plane + src0] : 0.f;
     };
 
     // B operand of N-tile nt: window position p = 16 nt + n of this wave's tile (row-major, WCL per row), inside the workgroup's image
@@ -113,7 +115,7 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
                 for (int k = 0; k < kKC; ++k) img[k * P::CST + dst_off[e]] = pre[e][k];
             }
 #pragma unroll
-        for (int h = 0; h < NP0; ++h) img[(k0 + 4 * h) * P::CST + dst0] = pre0[h];
+        for (int h = 0; h < NP0; ++h) img[(k0 + KS * h) * P::CST + dst0] = pre0[h];
         __syncthreads();
         if (c0 + kKC < C) fetch(c0 + kKC);                           // in flight while this chunk is consumed
 #pragma unroll
@@ -145,7 +147,7 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
         }
     }
     __syncthreads();
-    const int ncols = W - j0 < 16 ? W - j0 : 16;
+    const int ncols = W - j0 < TW ? W - j0 : TW;
     for (int pi = 0; pi < 4; ++pi) {
         if (i0 + pi >= H) break;
         float* dst = out + ((size_t)(b * plane + (i0 + pi) * W + j0)) * P::CELLS;      // ncols * CELLS contiguous floats
@@ -156,13 +158,27 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     }
 }
 
+template <int D, int TP>
+int launch_fwd_mfma_tp(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int s, hipStream_t st)
+{
+    using P = FwdMfma<D, TP>;
+    const int grid = B * ((H + 3) / 4) * ((W + 4 * TP - 1) / (4 * TP));
+    if (P::LDS > 64 * 1024) D2T_ENSURE_DYNAMIC_LDS((k_corr_fwd_mfma<D, TP>), P::LDS);
+    hipLaunchKernelGGL((k_corr_fwd_mfma<D, TP>), dim3(grid), dim3(P::THREADS), P::LDS, st, fm0, fm1, out, B, C, H, W, s);
+    return launch_status();
+}
+
+#ifndef D2T_FWD_MFMA_TP
+#define D2T_FWD_MFMA_TP 0                                            // lab: 2 / 4 force the workgroup width
+#endif
 template <int D>
 int launch_fwd_mfma(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int s, hipStream_t st)
 {
-    const int grid = B * ((H + 3) / 4) * ((W + 15) / 16);
-    if (FwdMfma<D>::LDS > 64 * 1024) D2T_ENSURE_DYNAMIC_LDS(k_corr_fwd_mfma<D>, FwdMfma<D>::LDS);
-    hipLaunchKernelGGL(k_corr_fwd_mfma<D>, dim3(grid), dim3(FwdMfma<D>::THREADS), FwdMfma<D>::LDS, st, fm0, fm1, out, B, C, H, W, s);
-    return launch_status();
+    // two p-tiles per workgroup (4 x 8 pixels) unless d_max = 7 on a grid that fills the chip with four: B = 8, C = 256, 38 x 63, us,
+    // (two / four): d 4 45.6 / 51.3, d 6 63.0 / 67.0, d 7 125.7 / 118.2; d 7 at B = 1 54.0 / 61.9; B = 2, C = 1024, d 6 112 / 146
+    const long long grid4 = 1LL * B * ((H + 3) / 4) * ((W + 15) / 16);
+    const bool narrow = D2T_FWD_MFMA_TP ? D2T_FWD_MFMA_TP == 2 : (D <= 6 || grid4 < 256);
+    return narrow ? launch_fwd_mfma_tp<D, 2>(fm0, fm1, out, B, C, H, W, s, st) : launch_fwd_mfma_tp<D, 4>(fm0, fm1, out, B, C, H, W, s, st);
 }
 
 }  // namespace
