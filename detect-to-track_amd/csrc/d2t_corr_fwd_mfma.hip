@@ -186,7 +186,7 @@ int launch_fwd_mfma(const float* fm0, const float* fm1, float* out, int B, int C
 bool corr_fwd_mfma_supported(int B, int C, int H, int W, int d, int s)
 {
     // d_max <= 7: measured against k_corr_fwd_tiled at B = 8, C = 256, 38 x 63 (us): d 2: 36 / 45, 4: 52 / 65, 5: 64 / 79, 6: 67 / 81, 7: 118 / 124;
-    // d 8 (stride 2): 123 / 120 -- 25 N-tiles leave two waves per SIMD, the vector-ALU kernel keeps that case
+    // d 8 (stride 2): 119-124 / 120 either workgroup width -- 25 N-tiles leave two waves per SIMD, the vector-ALU kernel keeps that case
 #ifndef D2T_FWD_MFMA_MAXD
 #define D2T_FWD_MFMA_MAXD 7
 #endif
