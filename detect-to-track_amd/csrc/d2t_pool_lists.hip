@@ -18,9 +18,10 @@
 // 2-3 do nothing and the thread-per-pixel kernel, launched last and otherwise returning at once, does the work -- decided on
 // the device, no host synchronisation.
 //
-// PSROIPool backward the same way (k_ps_cover_build, k_psroipool_bwd_lists): there the list belongs to a (cell, pixel) pair -- the
-// RoIs whose cell (i, j) contains the pixel, ascending -- and serves every channel (t + 1) * bin that reads that cell
-// (ps_roipool_cuda.cu:58); k_psroipool_bwd_generic tested all R RoIs per (channel, pixel) and divisor of the channel.
+// PSROIPool backward the same way (k_ps_row_build, k_psroipool_bwd_rows): there a list belongs to a (cell, map row) pair -- the RoIs
+// whose cell (i, j) reaches that row, ascending, with the cell's column range -- and serves every pixel of the row and every channel
+// (t + 1) * bin that reads the cell (ps_roipool_cuda.cu:58); k_psroipool_bwd_generic tested all R RoIs per (channel, pixel) and
+// divisor of the channel.
 #include "d2t_kernels.hpp"
 
 namespace d2t {
@@ -133,99 +134,117 @@ k_cover_build(const int32_t* __restrict__ bins, u64* __restrict__ counter, int2*
     }
 }
 
-// PSROIPool: thread = (cell, pixel), lanes along x; its list = the RoIs (ascending) whose cell contains the pixel, with the
-// cell's area.  Two walks over the RoIs: count, take a run of the entry array, write.
+// PSROIPool: one list per (cell, map ROW) -- the RoIs (ascending) whose cell's rows contain that row and whose column range is not
+// empty, each with the cell's area and column range.  Workgroup = (cell, row), thread = RoI, ordered compaction by block scans; the
+// workgroup takes its run of the entry array with one atomic add.  (Round 4 first kept a list per (cell, PIXEL): R k^2 H W cell tests
+// to build, and a gather in which every lane walks its own list -- one cache line per lane and term: 130 us at R = 300, k = 6.)
 __global__ void __launch_bounds__(kBlk)
-k_ps_cover_build(const int32_t* __restrict__ cells, u64* __restrict__ counter, int2* __restrict__ heads, int2* __restrict__ entries,
-                 long long cap, int R, int HW, int W, int kk)
+k_ps_row_build(const int32_t* __restrict__ cells, u64* __restrict__ counter, int2* __restrict__ heads, int4* __restrict__ entries,
+               long long cap, int R, int H, int kk)
 {
     __shared__ int sh[4];
     const int4* ct = reinterpret_cast<const int4*>(cells);
-    const int id = blockIdx.x * kBlk + threadIdx.x;                   // list = bin * HW + pixel
-    const bool live = id < kk * HW;
-    const int bin = live ? id / HW : 0, p = live ? id - bin * HW : 0, y = p / W, x = p - y * W;
+    const int list = blockIdx.x, bin = list / H, y = list - bin * H;
     int n = 0;
-    if (live)
-        for (int r0 = 0; r0 < R; r0 += kAhead) {                      // kAhead cells' bounds in flight
-            int4 cb[kAhead];
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) cb[u] = ct[(size_t)(r0 + u < R ? r0 + u : r0) * kk + bin];
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) n += (r0 + u < R && y >= cb[u].x && y < cb[u].y && x >= cb[u].z && x < cb[u].w);
-        }
+    for (int r = threadIdx.x; r < R; r += kBlk) {
+        const int4 cb = ct[(size_t)r * kk + bin];
+        n += (y >= cb.x && y < cb.y && cb.w > cb.z);
+    }
     int total;
-    const int pre = block_exclusive_scan(n, sh, &total);
+    block_exclusive_scan(n, sh, &total);
     const long long start = block_take(counter, total, sh);
     const bool fits = start + total <= cap;
-    if (live) heads[id] = fits ? make_int2((int)start + pre, n) : make_int2(0, 0);
-    if (!fits || !live || n == 0) return;
-    int2* dst = entries + start + pre;
-    for (int r0 = 0; r0 < R; r0 += kAhead) {
-        int4 cb[kAhead];
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u) cb[u] = ct[(size_t)(r0 + u < R ? r0 + u : r0) * kk + bin];
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u)
-            if (r0 + u < R && y >= cb[u].x && y < cb[u].y && x >= cb[u].z && x < cb[u].w)
-                *dst++ = make_int2(r0 + u, (cb[u].y - cb[u].x) * (cb[u].w - cb[u].z));
+    if (threadIdx.x == 0) heads[list] = fits ? make_int2((int)start, total) : make_int2(0, 0);
+    if (!fits || total == 0) return;
+    int base = (int)start;
+    for (int r0 = 0; r0 < R; r0 += kBlk) {                            // RoIs ascending: 256 at a time, in thread order
+        const int r = r0 + threadIdx.x;
+        const int4 cb = ct[(size_t)(r < R ? r : 0) * kk + bin];
+        const int hit = r < R && y >= cb.x && y < cb.y && cb.w > cb.z;
+        int pass;
+        const int pos = base + block_exclusive_scan(hit, sh, &pass);
+        if (hit) entries[pos] = make_int4(r, (cb.y - cb.x) * (cb.w - cb.z), cb.z, cb.w);
+        base += pass;
     }
 }
 
-// gradIn[ch][y][x]: thread per (ch, pixel).  Channel ch receives from every (t, bin) with (t + 1) * bin == ch (ch == 0: bin 0 with
-// every t); bins ascending, then the list (RoIs ascending), then t -- the order of k_psroipool_bwd_generic; each term gradOut / n
-// (ps_roipool_cuda.cu:118-127 in gather form).
+__device__ __forceinline__ float lane_value(float v, int u) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), u)); }
+__device__ __forceinline__ double lane_value(double v, int u)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffLL), u), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), u);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// gradIn[ch][y][x0 .. x0 + 63]: one WAVE per (channel, row, 64 columns), a lane per column.  Channel ch receives from every (t, bin) with
+// (t + 1) * bin == ch (ch == 0: bin 0 with every t); bins ascending, then the row's list (RoIs ascending), then t -- the order of
+// k_psroipool_bwd_generic; each term gradOut / n (ps_roipool_cuda.cu:118-127 in gather form).  The list is the same for the whole wave:
+// 64 entries are loaded at once (lane = entry; its term gradOut / n is computed there) and handed round with v_readlane; a lane adds
+// the terms whose column range contains its column.  kMaxT: targets of channel 0 held per entry (more: a scalar walk).
+constexpr int kMaxT = 32;
+
 template <typename T>
-__global__ void __launch_bounds__(kBlk)
-k_psroipool_bwd_lists(const T* __restrict__ gout, const u64* __restrict__ counter, const int2* __restrict__ heads,
-                      const int2* __restrict__ entries, long long cap, T* __restrict__ gin, int nT, int HW, int kk)
+__global__ void __launch_bounds__(64)
+k_psroipool_bwd_rows(const T* __restrict__ gout, const u64* __restrict__ counter, const int2* __restrict__ heads,
+                     const int4* __restrict__ entries, long long cap, T* __restrict__ gin, int nT, int H, int W, int kk, int segs)
 {
     if ((long long)*counter > cap) return;
-    const long long total = 1LL * nT * kk * HW;
-    for (long long i64 = (long long)blockIdx.x * kBlk + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlk) {
-        const int ch = (int)(i64 / HW), p = (int)(i64 - (long long)ch * HW);
-        T acc = T(0);
-        const int bin_lo = ch == 0 ? 0 : 1, bin_hi = ch == 0 ? 0 : kk - 1;
-        for (int bin = bin_lo; bin <= bin_hi; ++bin) {
-            int t_lo, t_hi;
-            if (ch == 0) { t_lo = 0; t_hi = nT - 1; }
-            else {
-                if (ch % bin != 0) continue;
-                const int tp1 = ch / bin;
-                if (tp1 > nT) continue;
-                t_lo = t_hi = tp1 - 1;
-            }
-            const int2 h = heads[(size_t)bin * HW + p];
-            const int end = h.x + h.y;
-            if (t_lo == t_hi) {                                       // one target: four list entries' loads in flight, added in list order
-                for (int e = h.x; e < end; e += 4) {
-                    int2 rn[4];
-                    T g[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) rn[u] = entries[e + u < end ? e + u : e];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) g[u] = gout[((size_t)rn[u].x * nT + t_lo) * kk + bin];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (e + u < end) acc += g[u] / static_cast<T>(rn[u].y);
+    int wid = blockIdx.x;
+    const int seg = wid % segs; wid /= segs;
+    const int y = wid % H, ch = wid / H;
+    const int lane = threadIdx.x, x = seg * 64 + lane;
+    T acc = T(0);
+    // bins that divide ch with ch / bin <= nT: only bins in [ceil(ch / nT), min(ch, k^2 - 1)] can
+    const int bin_lo = ch == 0 ? 0 : (ch + nT - 1) / nT, bin_hi = ch == 0 ? 0 : (ch < kk - 1 ? ch : kk - 1);
+    for (int bin = bin_lo; bin <= bin_hi; ++bin) {
+        int t_lo, t_hi;
+        if (ch == 0) { t_lo = 0; t_hi = nT - 1; }
+        else {
+            const int tp1 = ch / bin;
+            if (tp1 * bin != ch) continue;
+            t_lo = t_hi = tp1 - 1;
+        }
+        const int2 h = heads[(size_t)bin * H + y];
+        const int end = h.x + h.y;
+        for (int e0 = h.x; e0 < end; e0 += 64) {
+            const int e = e0 + lane, cnt = end - e0 < 64 ? end - e0 : 64;
+            const int4 ent = e < end ? entries[e] : make_int4(0, 1, 0, 0);
+            const T dn = static_cast<T>(ent.y);
+            if (t_lo == t_hi) {
+                const T v = e < end ? gout[((size_t)ent.x * nT + t_lo) * kk + bin] / dn : T(0);
+                for (int u = 0; u < cnt; ++u) {                       // list order
+                    const int x0 = __builtin_amdgcn_readlane(ent.z, u), x1 = __builtin_amdgcn_readlane(ent.w, u);
+                    const T vv = lane_value(v, u);
+                    if (x >= x0 && x < x1) acc += vv;
                 }
-            } else {                                                  // channel 0: every target of every listed RoI, eight loads in flight
-                for (int e = h.x; e < end; ++e) {
-                    const int2 rn = entries[e];
-                    const T* gp = gout + (size_t)rn.x * nT * kk + bin;
-                    const T dn = static_cast<T>(rn.y);
-                    for (int t0 = t_lo; t0 <= t_hi; t0 += 8) {
-                        T g[8];
+            } else if (nT <= kMaxT) {                                 // channel 0: every target of every listed RoI, RoI-major
+                T v[kMaxT];
+                const T* gp = gout + (size_t)ent.x * nT * kk + bin;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) g[u] = gp[(size_t)(t0 + u <= t_hi ? t0 + u : t0) * kk];
+                for (int t = 0; t < kMaxT; ++t) v[t] = (e < end && t < nT) ? gp[(size_t)t * kk] / dn : T(0);
+                for (int u = 0; u < cnt; ++u) {
+                    const int x0 = __builtin_amdgcn_readlane(ent.z, u), x1 = __builtin_amdgcn_readlane(ent.w, u);
+                    const bool hit = x >= x0 && x < x1;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (t0 + u <= t_hi) acc += g[u] / dn;
+                    for (int t = 0; t < kMaxT; ++t)
+                        if (t < nT) {                                 // (uniform)
+                            const T vv = lane_value(v[t], u);
+                            if (hit) acc += vv;
+                        }
+                }
+            } else {
+                for (int u = 0; u < cnt; ++u) {
+                    const int r = __builtin_amdgcn_readlane(ent.x, u), nn = __builtin_amdgcn_readlane(ent.y, u);
+                    const int x0 = __builtin_amdgcn_readlane(ent.z, u), x1 = __builtin_amdgcn_readlane(ent.w, u);
+                    for (int t = t_lo; t <= t_hi; ++t) {
+                        const T vv = gout[((size_t)r * nT + t) * kk + bin] / static_cast<T>(nn);
+                        if (x >= x0 && x < x1) acc += vv;
                     }
                 }
             }
         }
-        gin[i64] = acc;
     }
+    if (x < W) gin[((size_t)ch * H + y) * W + x] = acc;
 }
 
 // Q[(r, bin)][c] = gradOut[r][c][bin] / n(r, bin).  Workgroup = (r, chunk of CH channels): CH * k^2 contiguous elements in,
@@ -315,15 +334,15 @@ ListsLayout lists_layout(int R, int C, int H, int W, int k)          // ROIPool:
     return L;
 }
 
-inline ListsLayout ps_lists_layout(int R, int H, int W, int k)       // PSROIPool: cells | counter | heads[kk HW] | entries (r, n)
+inline ListsLayout ps_lists_layout(int R, int H, int W, int k)       // PSROIPool: cells | counter | heads[kk H] | entries (r, n, j0, j1)
 {
     ListsLayout L;
-    L.cap = lists_cap(R, H, W, k);
+    L.cap = 1LL * R * k * (H + 2LL * k);                              // per RoI and cell column the cell rows cover <= H + 2k map rows
     L.bins = 0;
     L.counter = up256((size_t)R * k * k * 16);
     L.heads = L.counter + 256;
-    L.entries = L.heads + up256((size_t)k * k * H * W * 8);
-    L.q = L.total = L.entries + up256((size_t)L.cap * 8);
+    L.entries = L.heads + up256((size_t)k * k * H * 8);
+    L.q = L.total = L.entries + up256((size_t)L.cap * 16);
     return L;
 }
 
@@ -371,8 +390,8 @@ int roipool_bwd_lists(const T* gout, const T* rois, T* gin, void* ws, int R, int
 bool psroipool_bwd_lists_supported(int R, int nT, int H, int W, int k)
 {
     if (R < 1 || nT < 1 || H < 1 || W < 1 || k < 1) return false;
-    return lists_cap(R, H, W, k) < 0x4000000LL && 1LL * R * k * k < 0x7fffffffLL / 4 && fits_i32(1LL * R * nT * k * k) &&
-           fits_i32(1LL * nT * k * k * H * W) && 1LL * k * k * H * W < 0x8000000LL;
+    return 1LL * R * k * (H + 2LL * k) < 0x4000000LL && 1LL * R * k * k < 0x7fffffffLL / 4 && fits_i32(1LL * R * nT * k * k) &&
+           fits_i32(1LL * nT * k * k * H * W) && 1LL * k * k * H < 0x7fffffffLL && 1LL * nT * k * k * H * ((W + 63) / 64) < 0x7fffffffLL;
 }
 
 size_t psroipool_bwd_lists_ws_bytes(int R, int nT, int H, int W, int k)
@@ -388,14 +407,14 @@ int psroipool_bwd_lists(const T* gout, const T* rois, T* gin, void* ws, int R, i
     int32_t* cells = reinterpret_cast<int32_t*>(base + L.bins);
     u64* counter = reinterpret_cast<u64*>(base + L.counter);
     int2* heads = reinterpret_cast<int2*>(base + L.heads);
-    int2* entries = reinterpret_cast<int2*>(base + L.entries);
-    const int HW = H * W, kk = k * k;
+    int4* entries = reinterpret_cast<int4*>(base + L.entries);
+    const int kk = k * k, segs = (W + 63) / 64;
     int rc = psroipool_bins<T>(rois, cells, R, H, W, k, st);
     if (rc != D2T_OK) return rc;
     if (hipMemsetAsync(counter, 0, sizeof(u64), st) != hipSuccess) return launch_status();
-    hipLaunchKernelGGL(k_ps_cover_build, dim3((kk * HW + kBlk - 1) / kBlk), dim3(kBlk), 0, st, cells, counter, heads, entries, L.cap, R, HW, W, kk);
-    hipLaunchKernelGGL(k_psroipool_bwd_lists<T>, dim3(grid_for(1LL * nT * kk * HW, kBlk, 256 * 32)), dim3(kBlk), 0, st,
-                       gout, counter, heads, entries, L.cap, gin, nT, HW, kk);
+    hipLaunchKernelGGL(k_ps_row_build, dim3(kk * H), dim3(kBlk), 0, st, cells, counter, heads, entries, L.cap, R, H, kk);
+    hipLaunchKernelGGL(k_psroipool_bwd_rows<T>, dim3(nT * kk * H * segs), dim3(64), 0, st,
+                       gout, counter, heads, entries, L.cap, gin, nT, H, W, kk, segs);
     rc = launch_status();
     if (rc != D2T_OK) return rc;
     return psroipool_bwd_generic_gated<T>(gout, cells, gin, counter, L.cap, R, nT, H, W, k, st);

@@ -80,7 +80,7 @@ const char* d2t_error_string(int code);
  *                                                   f64: 1,217 / 2,068 (1,230 / 11,216)
  *   ROIPool R=300 C=1024 38x63    tuned 31 / 65     k=6: 29 / 166 (168 / 2,346)        f64: 264 / 299 (270 / 3,105)
  *                                 (forward: the summed-area kernel takes any k <= 16 -- within 1e-5 of the reference like k = 7)
- *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 131 (18 / 510)           f64: 25 / 184 (25 / 640)
+ *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 84 (18 / 510)            f64: 25 / 125 (25 / 640)
  * (the Python wrappers warn once when a float32 call leaves the envelope under D2T_IMPL_AUTO).
  *
  * Implementation selector of the f32 entry points (per call, no global state):

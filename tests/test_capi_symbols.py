@@ -81,7 +81,7 @@ def test_workspace_queries_cover_the_second_kernel_tier(native):
     assert lists >= R * Cp * k * k * 4 + R * (H + 2 * k) * (W + 2 * k) * 4 + R * k * k * 16
     assert L.d2t_roipool_bwd_workspace_bytes(R, Cp, H, W, k, 8) >= R * Cp * k * k * 8
     ps = L.d2t_psroipool_bwd_workspace_bytes(R, 21, H, W, k, 4)
-    assert ps >= R * (H + 2 * k) * (W + 2 * k) * 8 + k * k * H * W * 8
+    assert ps >= R * k * (H + 2 * k) * 16 + k * k * H * 8                       # (RoI, area, column range) per (cell, map row) + list heads
     # k = 7, f32: the tuned kernels' own (much smaller) scratch -- the lists are not asked for
     assert L.d2t_roipool_bwd_workspace_bytes(R, Cp, H, W, 7, 4) < R * Cp * 49 * 4
 
