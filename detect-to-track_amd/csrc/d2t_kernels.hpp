@@ -42,14 +42,15 @@ template <typename T> int    corr_bwd_blocked(const T* gout, const T* fm0, const
 bool corr_fwd_mfma_supported(int B, int C, int H, int W, int d, int s);
 int  corr_fwd_mfma_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int s, hipStream_t st);
 
-// ---- ROIPool backward outside the tuned envelope (d2t_pool_lists.hip): per-pixel bin lists built once, shared by all channels;
-// bit-identical to roipool_bwd_generic.  ws: bins | counter | list heads | list entries | gradOut / n by (bin, channel)
+// ---- ROIPool backward outside the tuned envelope (d2t_pool_lists.hip; k <= 32): per-row lists of (RoI, bin row) pairs + per-(RoI, column)
+// masks of bin columns, built once, shared by all channels; bit-identical to roipool_bwd_generic.
+// ws: bins | counter | list heads | list entries | column masks | gradOut / n by (bin, channel)
 template <typename T> bool   roipool_bwd_lists_supported(int R, int C, int H, int W, int k);
 template <typename T> size_t roipool_bwd_lists_ws_bytes(int R, int C, int H, int W, int k);
 template <typename T> int    roipool_bwd_lists(const T* gout, const T* rois, T* gin, void* ws, int R, int C, int H, int W, int k, hipStream_t st);
 template <typename T> int    roipool_bwd_generic_gated(const T* gout, const int32_t* bins, T* gin, const unsigned long long* gate, long long cap,
                                                        int R, int C, int H, int W, int k, hipStream_t st);
-// PSROIPool backward likewise: one list per (cell, pixel).  ws: cells | counter | list heads | list entries (RoI, cell area)
+// PSROIPool backward likewise: one list per (cell, map row).  ws: cells | counter | list heads | list entries (RoI, cell area, column range)
 bool   psroipool_bwd_lists_supported(int R, int nT, int H, int W, int k);
 size_t psroipool_bwd_lists_ws_bytes(int R, int nT, int H, int W, int k);
 template <typename T> int    psroipool_bwd_lists(const T* gout, const T* rois, T* gin, void* ws, int R, int nT, int H, int W, int k, hipStream_t st);

@@ -4,16 +4,17 @@
 // Which bins contain a pixel does not depend on the channel; the thread-per-(c, y, x) kernel re-derives it per channel
 // (C x H x W x R bin tests: 2.3 ms at R = 300, C = 1024, 38 x 63).  Here:
 //
-//   1. k_cover_build   per pixel, the list of the bins (r, i, j) that contain it, ascending, built once (workgroup = pixel,
-//      thread = RoI; membership is separable: row bins of r that contain y times column bins that contain x).  A workgroup
-//      counts, takes its run of the entry array with ONE atomic add on a counter (where a list lies is arbitrary, what it holds
-//      and in which order is not), then writes;
+//   1. k_roi_row_build / k_roi_col_masks   membership is separable (row bins of r that contain y times column bins that contain x):
+//      per map ROW the ascending list of the (RoI, bin row) pairs that contain it (workgroup = row, thread = RoI, block scans, ONE
+//      atomic add on a counter for the workgroup's run of the entry array -- where a list lies is arbitrary, what it holds and in
+//      which order is not), and per (RoI, column) a bit mask of the bin columns that contain it;
 //   2. k_grad_by_bin   Q[(r, i, j)][c] = gradOut[r][c][i][j] / n(r, i, j): the division of :123 done once per gradOut element
 //      instead of once per pixel of its bin, and the channel made the contiguous index;
-//   3. k_roipool_bwd_lists   workgroup = pixel, thread = channel: gradIn[c][y][x] = sum over the pixel's list of Q[bin][c] --
-//      the list entry is wave-uniform, the loads are coalesced along c.
+//   3. k_roipool_bwd_rows   workgroup = pixel, thread = channel: the pixel's bins (r, i, j), ascending, come out of its row's list and
+//      the column masks 256 entries at a time (into LDS); gradIn[c][y][x] = sum over them of Q[bin][c] -- the entry is uniform, the
+//      loads are coalesced along c.  (First version: a list per PIXEL, R x H x W RoI tests to build -- 62 us of 166 at R = 300.)
 //
-// The lists live in the caller's workspace, sized for RoIs no larger than the map (R (H + 2k)(W + 2k) entries).  RoIs far larger
+// The lists live in the caller's workspace, sized for RoIs no larger than the map (R (H + 2k) entries; k <= 32).  RoIs far larger
 // than the map can exceed that (every bin of such a RoI covers the whole map): the counter then ends above the capacity, steps
 // 2-3 do nothing and the thread-per-pixel kernel, launched last and otherwise returning at once, does the work -- decided on
 // the device, no host synchronisation.
@@ -65,16 +66,6 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total)
     return incl - v + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
 }
 
-// does RoI r reach pixel (y, x) at all?  Bin edges are monotone in the bin index (DEcreasing for a RoI of negative extent, whose
-// bins run in reverse order): the overall extent is the min / max over the first and the last bin (as in k_roipool_bwd_generic).
-__device__ __forceinline__ bool roi_reaches(const int4* __restrict__ br, int kk, int y, int x)
-{
-    const int4 bf = br[0], bl = br[kk - 1];
-    const int y_lo = bf.x < bl.x ? bf.x : bl.x, y_hi = bf.y > bl.y ? bf.y : bl.y;
-    const int x_lo = bf.z < bl.z ? bf.z : bl.z, x_hi = bf.w > bl.w ? bf.w : bl.w;
-    return y >= y_lo && y < y_hi && x >= x_lo && x < x_hi;
-}
-
 typedef unsigned long long u64;
 
 // the workgroup's `total` entries: one atomic add, result broadcast (sh: 4 ints, reused)
@@ -88,49 +79,54 @@ __device__ __forceinline__ long long block_take(u64* counter, int total, int* sh
     return v;
 }
 
+// ROIPool: one list per map ROW -- the (RoI, bin row) pairs r * k + i whose bin row contains the row, ascending.  Workgroup = row,
+// thread = RoI, ordered compaction by block scans, one atomic add for the workgroup's run of the entry array.
 __global__ void __launch_bounds__(kBlk)
-k_cover_build(const int32_t* __restrict__ bins, u64* __restrict__ counter, int2* __restrict__ heads, int32_t* __restrict__ entries,
-              long long cap, int R, int H, int W, int k)
+k_roi_row_build(const int32_t* __restrict__ bins, u64* __restrict__ counter, int2* __restrict__ heads, int32_t* __restrict__ entries,
+                long long cap, int R, int k)
 {
     __shared__ int sh[4];
     const int4* bt = reinterpret_cast<const int4*>(bins);
-    const int p = blockIdx.x, y = p / W, x = p - y * W;
+    const int y = blockIdx.x;
     int n = 0;
-    for (int r = threadIdx.x; r < R; r += kBlk) {
-        const int4* br = bt + (size_t)r * k * k;
-        if (!roi_reaches(br, k * k, y, x)) continue;
-        const int ni = axis_hits(br, k, k, y, true);
-        if (ni) n += ni * axis_hits(br, 1, k, x, false);
-    }
+    for (int r = threadIdx.x; r < R; r += kBlk) n += axis_hits(bt + (size_t)r * k * k, k, k, y, true);
     int total;
     block_exclusive_scan(n, sh, &total);
     const long long start = block_take(counter, total, sh);
     const bool fits = start + total <= cap;
-    if (threadIdx.x == 0) heads[p] = fits ? make_int2((int)start, total) : make_int2(0, 0);
+    if (threadIdx.x == 0) heads[y] = fits ? make_int2((int)start, total) : make_int2(0, 0);
     if (!fits || total == 0) return;                                  // (no list: the thread-per-pixel kernel runs instead)
     int base = (int)start;
     for (int r0 = 0; r0 < R; r0 += kBlk) {                            // RoIs ascending: 256 at a time, in thread order
         const int r = r0 + threadIdx.x;
         const int4* br = bt + (size_t)(r < R ? r : 0) * k * k;
-        int ni = 0, nj = 0;
-        if (r < R && roi_reaches(br, k * k, y, x)) {
-            ni = axis_hits(br, k, k, y, true);
-            if (ni) nj = axis_hits(br, 1, k, x, false);
-        }
+        const int ni = r < R ? axis_hits(br, k, k, y, true) : 0;
         int pass;
-        int pos = base + block_exclusive_scan(ni * nj, sh, &pass);
-        if (ni * nj) {
-            for (int i = 0; i < k; ++i) {                             // (i, j) ascending
+        int pos = base + block_exclusive_scan(ni, sh, &pass);
+        if (ni)
+            for (int i = 0; i < k; ++i) {                             // bin rows ascending
                 const int4 bi = br[i * k];
-                if (y < bi.x || y >= bi.y) continue;
-                for (int j = 0; j < k; ++j) {
-                    const int4 bj = br[j];
-                    if (x < bj.z || x >= bj.w) continue;
-                    entries[pos++] = (r * k + i) * k + j;
-                }
+                if (y >= bi.x && y < bi.y) entries[pos++] = r * k + i;
             }
-        }
         base += pass;
+    }
+}
+
+// colmask[r][x]: bit j set iff column x lies in bin column j of RoI r (k <= 32; column bounds depend on (r, j) only, roipool_cuda.cu:46-50)
+__global__ void __launch_bounds__(kBlk)
+k_roi_col_masks(const int32_t* __restrict__ bins, uint32_t* __restrict__ colmask, int R, int W, int k)
+{
+    const int4* bt = reinterpret_cast<const int4*>(bins);
+    const int total = R * W;
+    for (int id = blockIdx.x * kBlk + threadIdx.x; id < total; id += gridDim.x * kBlk) {
+        const int r = id / W, x = id - r * W;
+        const int4* br = bt + (size_t)r * k * k;
+        uint32_t m = 0;
+        for (int j = 0; j < k; ++j) {
+            const int4 b = br[j];
+            m |= (x >= b.z && x < b.w) ? 1u << j : 0u;
+        }
+        colmask[id] = m;
     }
 }
 
@@ -273,16 +269,23 @@ k_grad_by_bin(const T* __restrict__ gout, const int32_t* __restrict__ bins, cons
     }
 }
 
-// gradIn[c][y][x] = sum over the pixel's list, in list order, of Q[entry][c].  Workgroup = pixel; a thread owns the channels
-// tid, tid + 256, tid + 512, tid + 768 of each group of 1024.
+// gradIn[c][y][x] = sum, ascending (r, i, j), of Q[(r, i, j)][c] over the bins that contain the pixel.  Workgroup = pixel; a thread owns
+// the channels tid, tid + 256, tid + 512, tid + 768 of each group of 1024.  The pixel's bins come out of its ROW's list 256 entries at
+// a time (thread = entry: the RoI's column mask at x says which bin columns j contain the pixel; a block scan orders the hits
+// (r, i, j) into an LDS buffer), then every thread walks the buffer -- uniform entries, loads coalesced along c, kAhead in flight.
 template <typename T>
 __global__ void __launch_bounds__(kBlk)
-k_roipool_bwd_lists(const T* __restrict__ q, const u64* __restrict__ counter, const int2* __restrict__ heads,
-                    const int32_t* __restrict__ entries, long long cap, T* __restrict__ gin, int C, int HW)
+k_roipool_bwd_rows(const T* __restrict__ q, const u64* __restrict__ counter, const int2* __restrict__ heads,
+                   const int32_t* __restrict__ entries, const uint32_t* __restrict__ colmask, long long cap,
+                   T* __restrict__ gin, int C, int H, int W, int k)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ int sh[4];
     if ((long long)*counter > cap) return;
-    const int p = xcd_run(blockIdx.x, HW);                            // neighbouring pixels (nearly the same lists) share an L2
-    const int2 h = heads[p];
+    int* hits = reinterpret_cast<int*>(lds_raw);                      // [kBlk * k]: Q row indices (r * k + i) * k + j of one chunk
+    const int HW = H * W;
+    const int p = xcd_run(blockIdx.x, HW), y = p / W, x = p - y * W;  // neighbouring pixels (nearly the same bins) share an L2
+    const int2 h = heads[y];
     const int beg = h.x, end = h.x + h.y;
     for (int c0 = 0; c0 < C; c0 += 4 * kBlk) {
         const int c = c0 + threadIdx.x;
@@ -290,20 +293,34 @@ k_roipool_bwd_lists(const T* __restrict__ q, const u64* __restrict__ counter, co
         bool has[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) has[m] = c + m * kBlk < C;
-        for (int e = beg; e < end; e += kAhead) {                     // kAhead list entries' loads in flight, added in list order
-            T v[kAhead][4];
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) {
-                const T* row = q + (size_t)entries[e + u < end ? e + u : e] * C + c;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) v[u][m] = has[m] ? row[m * kBlk] : T(0);
+        for (int e0 = beg; e0 < end; e0 += kBlk) {
+            const int e = e0 + threadIdx.x;
+            const int ent = e < end ? entries[e] : 0;
+            uint32_t m = e < end ? colmask[(size_t)(ent / k) * W + x] : 0u;
+            int total;
+            int pos = block_exclusive_scan(__builtin_popcount(m), sh, &total);
+            while (m) {                                               // bin columns ascending
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                hits[pos++] = ent * k + j;
             }
+            __syncthreads();
+            for (int t0 = 0; t0 < total; t0 += kAhead) {              // kAhead bins' loads in flight, added in (r, i, j) order
+                T v[kAhead][4];
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u)
-                if (e + u < end) {
+                for (int u = 0; u < kAhead; ++u) {
+                    const T* row = q + (size_t)hits[t0 + u < total ? t0 + u : t0] * C + c;
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m] += v[u][m];
+                    for (int mm = 0; mm < 4; ++mm) v[u][mm] = has[mm] ? row[mm * kBlk] : T(0);
                 }
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u)
+                    if (t0 + u < total) {
+#pragma unroll
+                        for (int mm = 0; mm < 4; ++mm) acc[mm] += v[u][mm];
+                    }
+            }
+            __syncthreads();                                          // the buffer is free again
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -314,22 +331,21 @@ k_roipool_bwd_lists(const T* __restrict__ q, const u64* __restrict__ counter, co
 inline size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 
 struct ListsLayout {
-    size_t bins, counter, heads, entries, q, total;
+    size_t bins, counter, heads, entries, masks, q, total;
     long long cap;
 };
 
-inline long long lists_cap(int R, int H, int W, int k) { return 1LL * R * (H + 2LL * k) * (W + 2LL * k); }
-
 template <typename T>
-ListsLayout lists_layout(int R, int C, int H, int W, int k)          // ROIPool: bins | counter | heads[HW] | entries | Q
+ListsLayout lists_layout(int R, int C, int H, int W, int k)          // ROIPool: bins | counter | heads[H] | entries | column masks | Q
 {
     ListsLayout L;
-    L.cap = lists_cap(R, H, W, k);
+    L.cap = 1LL * R * (H + 2LL * k);                                  // a RoI's bin rows cover <= H + 2k map rows between them
     L.bins = 0;
     L.counter = up256((size_t)R * k * k * 16);
     L.heads = L.counter + 256;
-    L.entries = L.heads + up256((size_t)H * W * 8);
-    L.q = L.entries + up256((size_t)L.cap * 4);
+    L.entries = L.heads + up256((size_t)H * 8);
+    L.masks = L.entries + up256((size_t)L.cap * 4);
+    L.q = L.masks + up256((size_t)R * W * 4);
     L.total = L.q + up256((size_t)R * C * k * k * sizeof(T));
     return L;
 }
@@ -352,8 +368,8 @@ template <typename T>
 bool roipool_bwd_lists_supported(int R, int C, int H, int W, int k)
 {
     if (R < 1 || C < 1 || H < 1 || W < 1 || k < 1) return false;
-    return lists_cap(R, H, W, k) < 0x4000000LL && 1LL * R * k * k < 0x7fffffffLL / 4 && fits_i32(1LL * R * C * k * k) &&
-           fits_i32(1LL * C * H * W) && (size_t)k * k * sizeof(T) <= 16 * 1024;
+    return k <= 32 && 1LL * R * (H + 2LL * k) < 0x4000000LL && 1LL * R * k * k < 0x7fffffffLL / 4 && fits_i32(1LL * R * C * k * k) &&
+           fits_i32(1LL * C * H * W) && fits_i32(1LL * R * W);
 }
 
 template <typename T>
@@ -371,17 +387,20 @@ int roipool_bwd_lists(const T* gout, const T* rois, T* gin, void* ws, int R, int
     u64* counter = reinterpret_cast<u64*>(base + L.counter);
     int2* heads = reinterpret_cast<int2*>(base + L.heads);
     int32_t* entries = reinterpret_cast<int32_t*>(base + L.entries);
+    uint32_t* masks = reinterpret_cast<uint32_t*>(base + L.masks);
     T* q = reinterpret_cast<T*>(base + L.q);
     const int HW = H * W, kk = k * k;
     int rc = roipool_bins<T>(rois, bins, R, H, W, k, st);
     if (rc != D2T_OK) return rc;
     if (hipMemsetAsync(counter, 0, sizeof(u64), st) != hipSuccess) return launch_status();
-    hipLaunchKernelGGL(k_cover_build, dim3(HW), dim3(kBlk), 0, st, bins, counter, heads, entries, L.cap, R, H, W, k);
+    hipLaunchKernelGGL(k_roi_row_build, dim3(H), dim3(kBlk), 0, st, bins, counter, heads, entries, L.cap, R, k);
+    hipLaunchKernelGGL(k_roi_col_masks, dim3(grid_for(1LL * R * W, kBlk)), dim3(kBlk), 0, st, bins, masks, R, W, k);
     int CH = 64;
     while (CH > 1 && (size_t)CH * (kk + 1) * sizeof(T) > 32 * 1024) CH >>= 1;
     hipLaunchKernelGGL(k_grad_by_bin<T>, dim3(R * ((C + CH - 1) / CH)), dim3(kBlk), (size_t)CH * (kk + 1) * sizeof(T), st,
                        gout, bins, counter, L.cap, q, R, C, kk, k, CH);
-    hipLaunchKernelGGL(k_roipool_bwd_lists<T>, dim3(HW), dim3(kBlk), 0, st, q, counter, heads, entries, L.cap, gin, C, HW);
+    hipLaunchKernelGGL(k_roipool_bwd_rows<T>, dim3(HW), dim3(kBlk), (size_t)kBlk * k * sizeof(int), st, q, counter, heads, entries, masks, L.cap,
+                       gin, C, H, W, k);
     rc = launch_status();
     if (rc != D2T_OK) return rc;
     return roipool_bwd_generic_gated<T>(gout, bins, gin, counter, L.cap, R, C, H, W, k, st);   // runs only if the lists overflowed

@@ -73,12 +73,12 @@ const char* d2t_error_string(int code);
  * results are bit-identical to the thread-per-element kernels D2T_IMPL_GENERIC selects (tested), in two tiers: the default
  * dispatch takes kernels that share the work the anchor repeats per thread (correlation f32, d_max <= 14: d2t_corr_fwd_mfma.hip /
  * d2t_corr_blocked.hip -- forward tiles with the FM1 window in LDS (d_max <= 7: on the f32 matrix pipe), backward four pixels x four
- * channels per thread from zero-padded row copies; pooling backward: d2t_pool_lists.hip -- per-pixel lists of the bins / RoIs that contain the pixel, built once and shared
- * by all channels), D2T_IMPL_GENERIC the thread-per-element anchors.  Measured on an MI355X (tools/envelope_cost.py, us forward /
+ * channels per thread from zero-padded row copies; pooling backward, k <= 32: d2t_pool_lists.hip -- per map row the lists of the bin rows / cells
+ * that reach it, built once and shared by the row's pixels and all channels), D2T_IMPL_GENERIC the thread-per-element anchors.  Measured on an MI355X (tools/envelope_cost.py, us forward /
  * backward; thread-per-element anchor in brackets):
  *   correlation B=8 C=256 38x63   tuned 46 / 74     d_max=7: 120 / 197 (668 / 6,743)   stride 2: 131 / 210 (787 / 2,539)
  *                                                   f64: 1,217 / 2,068 (1,230 / 11,216)
- *   ROIPool R=300 C=1024 38x63    tuned 31 / 65     k=6: 29 / 166 (168 / 2,346)        f64: 264 / 299 (270 / 3,105)
+ *   ROIPool R=300 C=1024 38x63    tuned 31 / 65     k=6: 29 / 121 (168 / 2,346)        f64: 262 / 243 (270 / 3,105)
  *                                 (forward: the summed-area kernel takes any k <= 16 -- within 1e-5 of the reference like k = 7)
  *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 84 (18 / 510)            f64: 25 / 125 (25 / 640)
  * (the Python wrappers warn once when a float32 call leaves the envelope under D2T_IMPL_AUTO).
@@ -168,9 +168,9 @@ int d2t_corr_bwd_levels_f32(int n_levels, const float* const* gout, const float*
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
 
 /* ---------------- ROIPool (average) ----------------
- * Backward outside the tuned envelope (k != 7, f64): d2t_roipool_bwd_workspace_bytes covers the per-pixel bin lists and the
+ * Backward outside the tuned envelope (k != 7, f64; k <= 32): d2t_roipool_bwd_workspace_bytes covers the per-row bin lists and the
  * (bin, channel) copy of gradOut / n of d2t_pool_lists.hip (about the size of gradOut); a caller that passes only the R k^2 16
- * bytes of the bin table gets the thread-per-pixel kernel -- same values, ~14x slower.  PSROIPool likewise. */
+ * bytes of the bin table gets the thread-per-pixel kernel -- same values, ~20x slower.  PSROIPool likewise. */
 size_t d2t_roipool_fwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size);
 size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int elem_size);
 

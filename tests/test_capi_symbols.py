@@ -78,7 +78,7 @@ def test_workspace_queries_cover_the_second_kernel_tier(native):
     assert L.d2t_corr_bwd_workspace_bytes(B, C, H, W, 7, 1, 8) >= B * H * W * cells7 * 8     # f64: blocked
     R, Cp, k = 300, 1024, 6
     lists = L.d2t_roipool_bwd_workspace_bytes(R, Cp, H, W, k, 4)
-    assert lists >= R * Cp * k * k * 4 + R * (H + 2 * k) * (W + 2 * k) * 4 + R * k * k * 16
+    assert lists >= R * Cp * k * k * 4 + R * (H + 2 * k) * 4 + R * W * 4 + R * k * k * 16    # gradOut / n by (bin, channel), row lists, column masks, bins
     assert L.d2t_roipool_bwd_workspace_bytes(R, Cp, H, W, k, 8) >= R * Cp * k * k * 8
     ps = L.d2t_psroipool_bwd_workspace_bytes(R, 21, H, W, k, 4)
     assert ps >= R * k * (H + 2 * k) * 16 + k * k * H * 8                       # (RoI, area, column range) per (cell, map row) + list heads
