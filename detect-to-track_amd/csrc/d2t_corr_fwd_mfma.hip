@@ -24,7 +24,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKC = 8;                                               // channels per staged chunk (two MFMA k-steps; 16: 114 against 118 us at
-                                                                     // d_max 7 for 60 more registers -- not taken)
+                                                                     // d_max 7 for 60 more registers -- not taken; forcing the
+                                                                     // d_max 7 kernel into 128 registers for four waves per SIMD spills: 185 us)
 
 template <int D, int TP>                                          // TP: 4 x 4 p-tiles side by side per workgroup (4 or 2)
 struct FwdMfma {
@@ -40,7 +41,7 @@ struct FwdMfma {
     static constexpr int WIMG = WR * WCP;
     static constexpr int CST = ((WIMG + PX + 15) & ~15) + 16;       // floats per staged channel (+16: the four channels of a k-step on different banks)
     static constexpr int NPOS = (WIMG + THREADS - 1) / THREADS;     // window elements per thread and channel
-    static constexpr size_t LDS_LOOP = (size_t)kKC * CST * sizeof(float);
+    static constexpr size_t LDS_LOOP = (size_t)2 * kKC * CST * sizeof(float);      // two chunk images
     static constexpr size_t LDS_EPI = (size_t)PX * CELLS * sizeof(float);
     static constexpr size_t LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
 };
@@ -105,27 +106,40 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
 #pragma unroll
     for (int nt = 0; nt < P::NTW; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
-    for (int c0 = 0; c0 < C; c0 += kKC) {
-        __syncthreads();                                             // previous chunk consumed
+    // Two chunk images: chunk n + 1 is written (from the registers it was fetched into during chunk n - 1) while other waves still
+    // multiply chunk n -- one barrier per chunk.
+    auto stash = [&](float* buf) {
 #pragma unroll
         for (int e = 0; e < P::NPOS; ++e)
             if (dst_off[e] >= 0) {
 #pragma unroll
-                for (int k = 0; k < kKC; ++k) img[k * P::CST + dst_off[e]] = pre[e][k];
+                for (int k = 0; k < kKC; ++k) buf[k * P::CST + dst_off[e]] = pre[e][k];
             }
 #pragma unroll
-        for (int h = 0; h < NP0; ++h) img[(k0 + KS * h) * P::CST + dst0] = pre0[h];
-        __syncthreads();
-        if (c0 + kKC < C) fetch(c0 + kKC);                           // in flight while this chunk is consumed
+        for (int h = 0; h < NP0; ++h) buf[(k0 + KS * h) * P::CST + dst0] = pre0[h];
+    };
+    constexpr int IMG = kKC * P::CST;                                 // floats per chunk image
+    fetch(0);
+    stash(img);
+    if (kKC < C) fetch(kKC);
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < C; c0 += kKC) {
+        const float* now = img + cur * IMG;
+        if (c0 + kKC < C) {
+            stash(img + (cur ^ 1) * IMG);                            // chunk c0 + KC: its image was last read before the previous barrier
+            if (c0 + 2 * kKC < C) fetch(c0 + 2 * kKC);               // in flight while this chunk is consumed
+        }
 #pragma unroll
         for (int ks = 0; ks < kKC / 4; ++ks) {                       // ascending channels: 4 per MFMA
-            const float* ch = img + 4 * ks * P::CST;
+            const float* ch = now + 4 * ks * P::CST;
             const float a = ch[aoff];
 #pragma unroll
             for (int nt = 0; nt < P::NTW; ++nt)                       // (N-tiles past the window's end: clamped operands, results dropped)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ch[boff[nt]], acc[nt], 0, 0, 0);
         }
+        __syncthreads();                                             // chunk c0 consumed, chunk c0 + KC published
+        cur ^= 1;
     }
     __syncthreads();                                                 // the chunk image becomes the output image [tile][pixel][cell]
 
