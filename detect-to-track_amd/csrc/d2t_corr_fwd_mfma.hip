@@ -190,9 +190,11 @@ int launch_fwd_mfma(const float* fm0, const float* fm1, float* out, int B, int C
 {
     // two p-tiles per workgroup (4 x 8 pixels) unless d_max = 7 on a grid that fills the chip with four: B = 8, C = 256, 38 x 63, us,
     // (two / four): d 4 45.6 / 51.3, d 6 63.0 / 67.0, d 7 125.7 / 118.2; d 7 at B = 1 54.0 / 61.9; B = 2, C = 1024, d 6 112 / 146
+    // (three p-tiles, 480 workgroups at the d 7 shape: 117.0 -- no better than four)
     const long long grid4 = 1LL * B * ((H + 3) / 4) * ((W + 15) / 16);
-    const bool narrow = D2T_FWD_MFMA_TP ? D2T_FWD_MFMA_TP == 2 : (D <= 6 || grid4 < 256);
-    return narrow ? launch_fwd_mfma_tp<D, 2>(fm0, fm1, out, B, C, H, W, s, st) : launch_fwd_mfma_tp<D, 4>(fm0, fm1, out, B, C, H, W, s, st);
+    const int tp = D2T_FWD_MFMA_TP ? D2T_FWD_MFMA_TP : (D <= 6 || grid4 < 256) ? 2 : 4;
+    if (tp == 2) return launch_fwd_mfma_tp<D, 2>(fm0, fm1, out, B, C, H, W, s, st);
+    return launch_fwd_mfma_tp<D, 4>(fm0, fm1, out, B, C, H, W, s, st);
 }
 
 }  // namespace
