@@ -7,7 +7,7 @@
 //
 // Reference semantics: pointwise_correlation_cuda.cu:84-107 (forward), :145-171 (backward).
 //
-// f32, d_max <= 14 -- the tiled kernels (forward, d_max <= 7: the same tiling on the f32 matrix pipe, d2t_corr_fwd_mfma.hip):
+// f32, d_max <= 14 -- the tiled kernels (forward, d_max <= 8: the same tiling on the f32 matrix pipe, d2t_corr_fwd_mfma.hip):
 //   forward   k_corr_fwd_tiled: workgroup = 4 x 8 pixels, the FM1 window and the tile's FM0 pixels in LDS per chunk of 8 / 16
 //             channels (next chunk in flight into registers); thread (pixel column, window row) owns a cell row of four pixels,
 //             one aligned 16-byte LDS read per 16 fused multiply-adds.  Each cell is still ONE ascending-channel fma chain (:105-107).
@@ -493,7 +493,7 @@ int corr_fwd_blocked(const T* fm0, const T* fm1, T* out, int B, int C, int H, in
 {
     const long long cw = 2LL * d + 1, total = 1LL * B * H * W * cw * ((cw + 3) / 4);
     if (total == 0) return D2T_OK;
-    if (sizeof(T) == 4 && corr_fwd_mfma_supported(B, C, H, W, d, s))                                             // d_max <= 7: the same tiling on the matrix pipe
+    if (sizeof(T) == 4 && corr_fwd_mfma_supported(B, C, H, W, d, s))                                             // d_max <= 8: the same tiling on the matrix pipe
         return corr_fwd_mfma_f32(reinterpret_cast<const float*>(fm0), reinterpret_cast<const float*>(fm1), reinterpret_cast<float*>(out), B, C, H, W, d, s, st);
     if (sizeof(T) == 4 && d <= kTiledMaxD && 1LL * B * ((H + 3) / 4) * ((W + 7) / 8) < 0x7fffffffLL)       // LDS-tiled form (f32)
         return corr_fwd_tiled_f32(reinterpret_cast<const float*>(fm0), reinterpret_cast<const float*>(fm1), reinterpret_cast<float*>(out), B, C, H, W, d, s, st);

@@ -1,10 +1,10 @@
-// d2t_corr_fwd_mfma.hip -- PointwiseCorrelation forward OUTSIDE the tuned envelope on the f32 matrix pipe: any d_max <= 7, any
+// d2t_corr_fwd_mfma.hip -- PointwiseCorrelation forward OUTSIDE the tuned envelope on the f32 matrix pipe: any d_max <= 8, any
 // stride, any map (reference layout).  Bit-identical to the thread-per-cell anchor kernel (d2t_generic.hip) and to the reference:
 // v_mfma_f32_16x16x4_f32 is, per output element, the ascending-k chain of fmaf the reference's channel loop is
 // (pointwise_correlation_cuda.cu:105-107; d2t_corr_tuned.hip states and tests the same for d_max = 8), successive MFMAs continue that
 // chain in ascending channel order, and the zero channels that pad C to a multiple of 4 add fma(0, 0, acc) = acc exactly.
 //
-// Workgroup = 4 x 16 (or 4 x 8) pixels = four (two) 4 x 4 pixel tiles side by side, one wave each (two from d_max 3 up: they split the
+// Workgroup = 4 x 8 pixels = two 4 x 4 pixel tiles side by side, one wave each (two from d_max 3, four from d_max 5 up: they split the
 // N-tiles).  Per chunk of 8 channels the union of their windows
 // ((4 + 2d) rows x (16 + 2d) columns of FM1, zero outside the map) and the workgroup's pixels of FM0 are staged in LDS (the next chunk is in
 // flight into registers meanwhile).  A wave multiplies its tile's 16 pixels (M) with ALL the positions of its tile's window, 16 at a
@@ -13,9 +13,9 @@
 // cells; the others (60 % useful at d_max = 7) are discarded.  The epilogue scatters the accumulators into an LDS image
 // [pixel][cell] -- structural zeros included: cells the reference's loops do not visit (:88-93) are written as 0 -- and the workgroup
 // stores whole pixel rows.  Measured against k_corr_fwd_tiled (d2t_corr_blocked.hip, the same tiling on the vector ALU) at B = 8,
-// C = 256, 38 x 63: d_max 7 118 against 124 us, d_max 4 52 against 65 us, d_max 2 36 against 45 us -- a chunk is 24
-// MFMAs per wave between two barriers, and staging + barriers cost twice what the MFMAs do; the tuned kernel's LDS-DMA ring is what
-// removes that, and it is built for d_max = 8 only.
+// C = 256, 38 x 63: d_max 7 90 against 124 us, d_max 4 43 against 65 us, d_max 2 36 against 45 us.  What it took (docs/lab_notebook.md R4-16):
+// small workgroups and few registers per wave -- with 23 N-tiles in one wave the kernel ran one wave per SIMD and 320 workgroups in two
+// rounds (145 us).
 #include "d2t_kernels.hpp"
 
 namespace d2t {
@@ -27,14 +27,18 @@ constexpr int kKC = 8;                                               // channels
                                                                      // d_max 7 for 60 more registers -- not taken; forcing the
                                                                      // d_max 7 kernel into 128 registers for four waves per SIMD spills: 185 us)
 
+#ifndef D2T_FWD_MFMA_W4
+#define D2T_FWD_MFMA_W4 12                                           // N-tiles from which FOUR waves share a p-tile (d_max 5 up)
+#endif
 template <int D, int TP>                                          // TP: 4 x 4 p-tiles side by side per workgroup (4 or 2)
 struct FwdMfma {
     static constexpr int CW = 2 * D + 1, CELLS = CW * CW;
     static constexpr int WR = 4 + 2 * D;                            // window rows
     static constexpr int WCL = (4 + 2 * D + 3) & ~3;                // a tile's window columns, padded
     static constexpr int NT = (WR * WCL + 15) / 16;                 // N-tiles of a tile's window
-    static constexpr int WPT = NT >= 8 ? 2 : 1;                     // waves per tile: they split the N-tiles (accumulators + operand offsets
-    static constexpr int NTW = (NT + WPT - 1) / WPT;                //  of 23-25 N-tiles leave one wave per SIMD: 172 + 88 registers at d_max 7)
+    static constexpr int WPT = NT >= D2T_FWD_MFMA_W4 ? 4 : NT >= 8 ? 2 : 1;   // waves per tile: they split the N-tiles (accumulators + operand offsets
+    static constexpr int NTW = (NT + WPT - 1) / WPT;                //  of 23 N-tiles in one wave: 172 + 88 registers = one wave per SIMD at d_max 7;
+                                                                    //  two waves: 184, two per SIMD, 120 us; four: 98, four per SIMD, 90 us)
     static constexpr int PX = 16 * TP;                             // pixels per workgroup
     static constexpr int THREADS = 64 * TP * WPT;
     static constexpr int WCP = (4 * TP + 2 * D + 3) & ~3;           // the workgroup's window columns, padded
@@ -80,7 +84,7 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     const int src0 = (i0 + pxi < H && j0 + pxj < W) ? (i0 + pxi) * W + j0 + pxj : -1;
     const int dst0 = P::WIMG + (pxj >> 2) * 16 + 4 * pxi + (pxj & 3);
     const int k0 = tid / P::PX;                                        // channels k0, k0 + KS, ... of the chunk
-    constexpr int KS = kThreads / P::PX, NP0 = kKC / KS;               // (KS = 4 or 8 with one / two waves per tile)
+    constexpr int KS = kThreads / P::PX, NP0 = (kKC + KS - 1) / KS;    // (KS = 4 / 8 / 16 with one / two / four waves per tile)
 
     float pre[P::NPOS][kKC], pre0[NP0];
     auto fetch = [&](int c0) {
@@ -91,7 +95,7 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
                 pre[e][k] = (src_off[e] >= 0 && c0 + k < C) ? f1b[(size_t)(c0 + k) * plane + src_off[e]] : 0.f;
 #pragma unroll
         for (int h = 0; h < NP0; ++h)
-            pre0[h] = (src0 >= 0 && c0 + k0 + KS * h < C) ? f0b[(size_t)(c0 + k0 + KS * h) * plane + src0] : 0.f;
+            pre0[h] = (src0 >= 0 && k0 + KS * h < kKC && c0 + k0 + KS * h < C) ? f0b[(size_t)(c0 + k0 + KS * h) * plane + src0] : 0.f;
     };
 
     // B operand of N-tile nt: window position p = 16 nt + n of this wave's tile (row-major, WCL per row), inside the workgroup's image
@@ -116,7 +120,8 @@ k_corr_fwd_mfma(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
                 for (int k = 0; k < kKC; ++k) buf[k * P::CST + dst_off[e]] = pre[e][k];
             }
 #pragma unroll
-        for (int h = 0; h < NP0; ++h) buf[(k0 + KS * h) * P::CST + dst0] = pre0[h];
+        for (int h = 0; h < NP0; ++h)
+            if (k0 + KS * h < kKC) buf[(k0 + KS * h) * P::CST + dst0] = pre0[h];
     };
     constexpr int IMG = kKC * P::CST;                                 // floats per chunk image
     fetch(0);
@@ -188,11 +193,9 @@ int launch_fwd_mfma_tp(const float* fm0, const float* fm1, float* out, int B, in
 template <int D>
 int launch_fwd_mfma(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int s, hipStream_t st)
 {
-    // two p-tiles per workgroup (4 x 8 pixels) unless d_max = 7 on a grid that fills the chip with four: B = 8, C = 256, 38 x 63, us,
-    // (two / four): d 4 45.6 / 51.3, d 6 63.0 / 67.0, d 7 125.7 / 118.2; d 7 at B = 1 54.0 / 61.9; B = 2, C = 1024, d 6 112 / 146
-    // (three p-tiles, 480 workgroups at the d 7 shape: 117.0 -- no better than four)
-    const long long grid4 = 1LL * B * ((H + 3) / 4) * ((W + 15) / 16);
-    const int tp = D2T_FWD_MFMA_TP ? D2T_FWD_MFMA_TP : (D <= 6 || grid4 < 256) ? 2 : 4;
+    // two p-tiles per workgroup (4 x 8 pixels).  B = 8, C = 256, 38 x 63, us, (two / four p-tiles): d 4 45.6 / 51.3, d 6 63.0 / 67.0, and with
+    // four waves per p-tile d 7 90.3 / 103.5; d 7 at B = 1 41.9 / 61.0; B = 2, C = 1024, d 6 86.5 / 146 (three p-tiles at d 7: no better)
+    const int tp = D2T_FWD_MFMA_TP ? D2T_FWD_MFMA_TP : 2;
     if (tp == 2) return launch_fwd_mfma_tp<D, 2>(fm0, fm1, out, B, C, H, W, s, st);
     return launch_fwd_mfma_tp<D, 4>(fm0, fm1, out, B, C, H, W, s, st);
 }
@@ -201,10 +204,9 @@ int launch_fwd_mfma(const float* fm0, const float* fm1, float* out, int B, int C
 
 bool corr_fwd_mfma_supported(int B, int C, int H, int W, int d, int s)
 {
-    // d_max <= 7: measured against k_corr_fwd_tiled at B = 8, C = 256, 38 x 63 (us): d 2: 36 / 45, 4: 52 / 65, 5: 64 / 79, 6: 67 / 81, 7: 118 / 124;
-    // d 8 (stride 2): 119-124 / 120 either workgroup width -- 25 N-tiles leave two waves per SIMD, the vector-ALU kernel keeps that case
+    // measured against k_corr_fwd_tiled at B = 8, C = 256, 38 x 63 (us): d 2: 36 / 45, 4: 43 / 65, 5: 53 / 79, 6: 54 / 81, 7: 90 / 124, 8 (stride 2): 95 / 120
 #ifndef D2T_FWD_MFMA_MAXD
-#define D2T_FWD_MFMA_MAXD 7
+#define D2T_FWD_MFMA_MAXD 8
 #endif
     return B >= 1 && C >= 1 && H >= 1 && W >= 1 && d >= 0 && d <= D2T_FWD_MFMA_MAXD && s >= 1 && 1LL * B * ((H + 3) / 4) * ((W + 15) / 16) < 0x7fffffffLL &&
            fits_i32(1LL * B * H * W * (2 * d + 1) * (2 * d + 1)) && fits_i32(1LL * C * H * W);
@@ -221,6 +223,7 @@ int corr_fwd_mfma_f32(const float* fm0, const float* fm1, float* out, int B, int
         case 5: return launch_fwd_mfma<5>(fm0, fm1, out, B, C, H, W, s, st);
         case 6: return launch_fwd_mfma<6>(fm0, fm1, out, B, C, H, W, s, st);
         case 7: return launch_fwd_mfma<7>(fm0, fm1, out, B, C, H, W, s, st);
+        case 8: return launch_fwd_mfma<8>(fm0, fm1, out, B, C, H, W, s, st);
         default: return D2T_EINVAL;
     }
 }

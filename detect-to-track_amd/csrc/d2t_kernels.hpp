@@ -38,7 +38,7 @@ template <typename T> int    corr_fwd_blocked(const T* fm0, const T* fm1, T* out
 template <typename T> int    corr_bwd_blocked(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1,
                                               int B, int C, int H, int W, int d, int s, void* ws, hipStream_t st);
 
-// ---- correlation forward outside the tuned envelope on the f32 matrix pipe (d2t_corr_fwd_mfma.hip): d_max <= 7, any stride / map; bit-identical
+// ---- correlation forward outside the tuned envelope on the f32 matrix pipe (d2t_corr_fwd_mfma.hip): d_max <= 8, any stride / map; bit-identical
 bool corr_fwd_mfma_supported(int B, int C, int H, int W, int d, int s);
 int  corr_fwd_mfma_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int s, hipStream_t st);
 

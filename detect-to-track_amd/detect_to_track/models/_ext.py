@@ -41,7 +41,7 @@ def _outside_envelope(kind: str, why: str, factor: str) -> None:
 def _check_corr_envelope(x: Tensor, d_max: int, stride: int, impl: int) -> None:
     if x.dtype == torch.float32 and impl == _native.IMPL_AUTO and x.numel() and (d_max != 8 or stride != 1 or x.shape[-1] < 20):
         _outside_envelope("PointwiseCorrelation", f"d_max = {d_max}, stride = {stride}, W = {x.shape[-1]} (tuned: d_max = 8, stride 1, W >= 20)",
-                          "about 2.7x slower, forward and backward")
+                          "about 2x (forward) / 2.7x (backward) slower")
 
 
 def _check_pool_envelope(kind: str, x: Tensor, k: int, impl: int) -> None:
