@@ -504,7 +504,6 @@ int corr_fwd_blocked(const T* fm0, const T* fm1, T* out, int B, int C, int H, in
 static int corr_bwd_tiled_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1, int B, int C, int H, int W,
                               int d, int s, int XT, float* goutT, hipStream_t st)
 {
-    constexpr int CT = 4;
     const long long cw = 2LL * d + 1, cells = cw * cw;
     const int Wp = tiled_pitch(W, d);
     const long long rows = 1LL * B * C * H;
@@ -516,6 +515,9 @@ static int corr_bwd_tiled_f32(const float* gout, const float* fm0, const float* 
                            rows, B, H, W, Wp, d);
     }
     const int nq = (int)(cw + 3 + 3) / 4;                             // 16-byte pieces spanning the four windows of a thread: 1 .. 8
+    // channels per thread: four; two from d_max 7 up at stride 1 (20+ row values per channel in registers: 138 -> ~90 VGPRs, five waves per
+    // SIMD).  B = 8, C = 256, 38 x 63, us (two / four): d 7 178 / 197, d 12 399 / 437, but d 6 163 / 142, d 5 126 / 120, d 8 stride 2 224 / 201
+    const int CT = (nq >= 5 && s == 1) ? 2 : 4;
     const int CB = (kBlk / (XT / 4)) * CT < 64 ? 64 : (kBlk / (XT / 4)) * CT;   // one channel pass per workgroup where C allows
     const size_t lds = ((size_t)XT * cells + 8) * sizeof(float);
     const int grid = B * H * ((W + XT - 1) / XT) * ((C + CB - 1) / CB);
@@ -525,10 +527,13 @@ static int corr_bwd_tiled_f32(const float* gout, const float* fm0, const float* 
         const float* S = pass ? pad0 : pad1;
         float* gx = pass ? g1 : g0;
         switch (nq) {
-#define D2T_TILED_S(N, M, U) hipLaunchKernelGGL((k_corr_bwd_tiled<M, N, CT, U>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, Wp, d, s, XT, CB)
-#define D2T_TILED(N) case N: if (pass) { if (s == 1) D2T_TILED_S(N, true, true); else D2T_TILED_S(N, true, false); } \
-                             else { if (s == 1) D2T_TILED_S(N, false, true); else D2T_TILED_S(N, false, false); } break;
-            D2T_TILED(1) D2T_TILED(2) D2T_TILED(3) D2T_TILED(4) D2T_TILED(5) D2T_TILED(6) D2T_TILED(7) D2T_TILED(8)
+#define D2T_TILED_S(N, M, U, CTV) hipLaunchKernelGGL((k_corr_bwd_tiled<M, N, CTV, U>), dim3(grid), dim3(kBlk), lds, st, G, S, gx, B, C, H, W, Wp, d, s, XT, CB)
+#define D2T_TILED(N) case N: if (pass) { if (s == 1) D2T_TILED_S(N, true, true, 4); else D2T_TILED_S(N, true, false, 4); } \
+                             else { if (s == 1) D2T_TILED_S(N, false, true, 4); else D2T_TILED_S(N, false, false, 4); } break;
+#define D2T_TILED2(N) case N: if (s == 1) { if (pass) D2T_TILED_S(N, true, true, 2); else D2T_TILED_S(N, false, true, 2); } \
+                              else { if (pass) D2T_TILED_S(N, true, false, 4); else D2T_TILED_S(N, false, false, 4); } break;
+            D2T_TILED(1) D2T_TILED(2) D2T_TILED(3) D2T_TILED(4) D2T_TILED2(5) D2T_TILED2(6) D2T_TILED2(7) D2T_TILED2(8)
+#undef D2T_TILED2
 #undef D2T_TILED
 #undef D2T_TILED_S
             default: return D2T_EINVAL;
