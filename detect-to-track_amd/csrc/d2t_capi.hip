@@ -53,6 +53,9 @@ inline size_t bins_bytes(int R, int k) { return align_up((size_t)R * k * k * 4 *
 
 extern "C" {
 
+// workspace pointers: 16-byte aligned (the kernels read and write 16-byte vectors and a 64-bit counter in it; any device allocation is)
+static inline bool ws_misaligned(const void* ws) { return (reinterpret_cast<uintptr_t>(ws) & 15u) != 0; }
+
 int d2t_version(void) { return 105; }   // 1.05: round 4 -- D2T_IMPL_FAST / MFMA_WIDE8 / MFMA_STRIP4, d2t_region_filter_batched_f32, d2t_corr_bwd_levels_workspace_bytes
 
 const char* d2t_error_string(int code)
@@ -84,6 +87,7 @@ int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int 
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::corr_fwd_supported(B, C, H, W, d, stride)) {
@@ -115,6 +119,7 @@ int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, floa
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
@@ -135,6 +140,7 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1, d
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (1LL * B * C * H * W > 0 && (!gfm0 || !gfm1)) return D2T_EINVAL;
@@ -174,6 +180,7 @@ int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* 
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)out, C, B, H, W, d, stride, layout, bstride);
     if (rc != D2T_OK) return rc;
     const int cells = (2 * d + 1) * (2 * d + 1), HW = H * W;
@@ -207,6 +214,7 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)gout, C, B, H, W, d, stride, layout, bstride);
     if (rc != D2T_OK) return rc;
     if (!gfm0 || !gfm1) return D2T_EINVAL;
@@ -248,6 +256,7 @@ int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, i
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_pool(fm, rois, out, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     // The tuned forward builds a summed-area table of every channel (the whole map is read once): for
@@ -274,6 +283,7 @@ int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::roipool_bwd_supported(R, C, H, W, k)) {
@@ -290,6 +300,7 @@ int d2t_roipool_bwd_f64(const double* gout, const double* rois, double* gin, int
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;
@@ -327,6 +338,7 @@ int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_ps(fm, rois, out, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && R > 0 && tuned::psroipool_fwd_supported(R, nT, H, W, k)) {
@@ -350,6 +362,7 @@ int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int 
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (impl != D2T_IMPL_GENERIC && tuned::psroipool_bwd_supported(R, nT, H, W, k)) {
@@ -366,6 +379,7 @@ int d2t_psroipool_bwd_f64(const double* gout, const double* rois, double* gin, i
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
     if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     if (R > 0 && (!ws || ws_bytes < bins_bytes(R, k))) return D2T_EWS;

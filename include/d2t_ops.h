@@ -27,7 +27,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are
  *     asynchronous, allocate nothing, synchronise nothing and are graph-capturable.
  *   - `ws` is caller-provided device scratch of at least the matching
- *     d2t_*_workspace_bytes(...) bytes (may be NULL when that returns 0).
+ *     d2t_*_workspace_bytes(...) bytes (may be NULL when that returns 0), 16-byte aligned
+ *     (D2T_EINVAL otherwise; every device allocation is).
  *   - Return value: 0 on success; a negative D2T_E* code for argument errors; a
  *     positive value is a hipError_t from the launch.  The library keeps no pointers
  *     after return and is re-entrant (autograd calls backward from another thread).  Its only

@@ -55,6 +55,9 @@ def test_argument_validation_without_device(native):
     need = L.d2t_roipool_bwd_workspace_bytes(3, 2, 10, 10, 5, 8)
     assert need >= 3 * 5 * 5 * 4 * 4
     assert L.d2t_psroipool_bwd_workspace_bytes(3, 2, 10, 10, 5, 8) >= 3 * 5 * 5 * 4 * 4
+    # a workspace pointer that is not 16-byte aligned is refused before anything touches the device
+    assert L.d2t_roipool_bwd_f32(16, 16, 16, 3, 2, 10, 10, 5, 0x1008, 1 << 20, 0, None) == EINVAL
+    assert L.d2t_corr_bwd_f32(16, 16, 16, 16, 16, 1, 2, 9, 9, 3, 1, 0x1004, 1 << 20, 0, None) == EINVAL
     # the tuned-only selector refuses shapes the tuned kernels do not take instead of silently falling back
     assert L.d2t_corr_fwd_f32(8, 8, 8, 1, 2, 10, 10, 3, 1, None, 0, 2, None) == EINVAL
     assert L.d2t_corr_fwd_f64(8, 8, 8, 1, 2, 38, 63, 8, 1, None, 0, 2, None) == EINVAL
