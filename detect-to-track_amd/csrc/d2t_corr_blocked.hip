@@ -284,28 +284,30 @@ k_corr_bwd_blocked(const T* __restrict__ G, const T* __restrict__ S, T* __restri
 __global__ void __launch_bounds__(kBlk)
 k_corr_bwd_prepass(const float* __restrict__ fm0, const float* __restrict__ fm1, const float* __restrict__ gout,
                    float* __restrict__ pad0, float* __restrict__ pad1, float* __restrict__ goutT,
-                   long long rows, int B, int H, int W, int Wp, int d)
+                   int rows, int B, int H, int W, int Wp, int d)
 {
+    // (32-bit index arithmetic: the launcher checks that both element counts fit.  The pass is 44 us at B = 8, C = 256, 38 x 63, d_max 7
+    //  either way: the re-index reads one cache line per element)
     if (blockIdx.y < 2) {
         const float* S = blockIdx.y ? fm1 : fm0;
         float* P = blockIdx.y ? pad1 : pad0;
-        const long long total = rows * Wp;
-        for (long long i64 = (long long)blockIdx.x * kBlk + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlk) {
-            const long long row = i64 / Wp;
-            const int col = (int)(i64 - row * Wp) - d;
-            P[i64] = (col >= 0 && col < W) ? S[row * W + col] : 0.f;
+        const unsigned total = (unsigned)rows * (unsigned)Wp;
+        for (unsigned i = blockIdx.x * kBlk + threadIdx.x; i < total; i += gridDim.x * kBlk) {
+            const unsigned row = i / (unsigned)Wp;
+            const int col = (int)(i - row * (unsigned)Wp) - d;
+            P[i] = (col >= 0 && col < W) ? S[row * (unsigned)W + (unsigned)col] : 0.f;
         }
         return;
     }
     const int cw = 2 * d + 1, cells = cw * cw, plane = H * W;
-    const long long total = 1LL * B * plane * cells;
-    for (long long i64 = (long long)blockIdx.x * kBlk + threadIdx.x; i64 < total; i64 += (long long)gridDim.x * kBlk) {
-        const int cell = (int)(i64 % cells);
-        const int pix = (int)(i64 / cells);
+    const unsigned total = (unsigned)B * (unsigned)plane * (unsigned)cells;
+    for (unsigned i = blockIdx.x * kBlk + threadIdx.x; i < total; i += gridDim.x * kBlk) {
+        const unsigned pix = i / (unsigned)cells;
+        const int cell = (int)(i - pix * (unsigned)cells);
         const int cj = cell % cw, ci = cell / cw;
-        const int x = pix % W, y = (pix / W) % H, b = pix / plane;
-        const int i = y - ci + d, j = x - cj + d;
-        goutT[i64] = (i >= 0 && i < H && j >= 0 && j < W) ? gout[((size_t)(b * plane + i * W + j)) * cells + cell] : 0.f;
+        const int x = (int)(pix % (unsigned)W), y = (int)((pix / (unsigned)W) % (unsigned)H), b = (int)(pix / (unsigned)plane);
+        const int ii = y - ci + d, j = x - cj + d;
+        goutT[i] = (ii >= 0 && ii < H && j >= 0 && j < W) ? gout[((size_t)(b * plane + ii * W + j)) * cells + cell] : 0.f;
     }
 }
 
@@ -512,7 +514,7 @@ static int corr_bwd_tiled_f32(const float* gout, const float* fm0, const float* 
     {
         const long long most = rows * Wp > 1LL * B * H * W * cells ? rows * Wp : 1LL * B * H * W * cells;
         hipLaunchKernelGGL(k_corr_bwd_prepass, dim3(grid_for(most, kBlk, 256 * 16), 3), dim3(kBlk), 0, st, fm0, fm1, gout, pad0, pad1, goutT,
-                           rows, B, H, W, Wp, d);
+                           (int)rows, B, H, W, Wp, d);
     }
     const int nq = (int)(cw + 3 + 3) / 4;                             // 16-byte pieces spanning the four windows of a thread: 1 .. 8
     // channels per thread: four; two from d_max 7 up at stride 1 (20+ row values per channel in registers: 138 -> ~90 VGPRs, five waves per
@@ -553,7 +555,7 @@ int corr_bwd_blocked(const T* gout, const T* fm0, const T* fm1, T* g0, T* g1, in
     const size_t lds = (size_t)XT * cells * sizeof(T);
     const int grid = B * H * ((W + XT - 1) / XT) * ((C + CB - 1) / CB);
     T* goutT = static_cast<T*>(ws);
-    if (sizeof(T) == 4 && d <= kTiledMaxD && XT >= 4)                 // register-tiled form (f32)
+    if (sizeof(T) == 4 && d <= kTiledMaxD && XT >= 4 && 1LL * B * C * H * tiled_pitch(W, d) < 0x7fffffffLL)   // register-tiled form (f32)
         return corr_bwd_tiled_f32(reinterpret_cast<const float*>(gout), reinterpret_cast<const float*>(fm0), reinterpret_cast<const float*>(fm1),
                                   reinterpret_cast<float*>(g0), reinterpret_cast<float*>(g1), B, C, H, W, d, s, XT, reinterpret_cast<float*>(goutT), st);
     hipLaunchKernelGGL((k_corr_bwd_blocked<T, false>), dim3(grid), dim3(kBlk), lds, st, gout, fm1, g0, B, C, H, W, d, s, XT, CB);
