@@ -77,7 +77,7 @@ const char* d2t_error_string(int code);
  * channels per thread from zero-padded row copies; pooling backward, k <= 32: d2t_pool_lists.hip -- per map row the lists of the bin rows / cells
  * that reach it, built once and shared by the row's pixels and all channels), D2T_IMPL_GENERIC the thread-per-element anchors.  Measured on an MI355X (tools/envelope_cost.py, us forward /
  * backward; thread-per-element anchor in brackets):
- *   correlation B=8 C=256 38x63   tuned 46 / 74     d_max=7: 93 / 178 (668 / 6,743)    stride 2: 102 / 209 (787 / 2,539)
+ *   correlation B=8 C=256 38x63   tuned 46 / 74     d_max=7: 93 / 170 (668 / 6,743)    stride 2: 101 / 200 (787 / 2,539)
  *                                                   f64: 1,217 / 2,068 (1,230 / 11,216)
  *   ROIPool R=300 C=1024 38x63    tuned 31 / 65     k=6: 29 / 121 (168 / 2,346)        f64: 262 / 243 (270 / 3,105)
  *                                 (forward: the summed-area kernel takes any k <= 16 -- within 1e-5 of the reference like k = 7)
