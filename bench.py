@@ -80,13 +80,13 @@ def host_threads():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(cfg, counts, budget_s=12.0):
+def cpu_baseline(cfg, counts, budget_s=12.0, threads=None):
     """Time the CPU oracle (a port: the reference has no CPU path, common/cpp_common.hpp:1) on
     the same workload: all host threads (the headline `value`) and one thread on a
     quarter-batch sample.  Checker code, used here ONLY as a baseline."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import numpy as np
-    threads = host_threads()
+    threads = threads or host_threads()
     import oracle as O
     O.set_threads(threads)
     rng = np.random.default_rng(0)
@@ -157,22 +157,31 @@ def launch_ranks(script, argv, n):
     GPU -- as a CHILD process, and hand its exit code back.  This parent never imports torch and never touches HIP (a
     process that has initialised the GPU must not be replaced or forked into ranks on this pool); the ranks inherit stdout,
     so rank 0's single JSON line is the only line printed."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), *argv]
+    # --standalone: torchrun's own c10d rendezvous on a port it binds itself (no bind-close-reuse race between this parent
+    # and the ranks); --local-addr 127.0.0.1 because the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), str(script), *argv]
     return subprocess.call(cmd, env=env)
 
 
 def whole_job_value(units_per_rank_step, world, steps, elapsed_s):
     """Aggregate throughput: every rank processes its own shard (weak scaling, no exchange)."""
     return world * units_per_rank_step * steps / elapsed_s
+
+
+def device_index(local_rank, backend, device_count):
+    """Which GPU a rank uses.  RCCL ("nccl"): one GPU per rank, LOCAL_RANK is the device (a rank without a GPU of its own is an
+    error, not a wrap-around: two ranks on one device would deadlock RCCL).  Rehearsal backends (gloo): ranks may share GPUs."""
+    if backend == "nccl":
+        if not 0 <= local_rank < device_count:
+            raise SystemExit(f"rank with LOCAL_RANK {local_rank} has no GPU of its own ({device_count} visible): "
+                             "launch one rank per GPU, or rehearse with --backend gloo")
+        return local_rank
+    return local_rank % max(1, device_count)
 
 
 class HipDevice:
@@ -184,13 +193,15 @@ class HipDevice:
         import torch
         from detect_to_track.models import _native       # raises ImportError if the HIP library is missing
         self.torch, self.native, self.lib, self.impl, self.backend = torch, _native, _native.lib, impl, backend
-        if backend != "nccl":                            # rehearsal (--backend gloo): the ranks may share a GPU
-            local_rank %= torch.cuda.device_count()
+        local_rank = device_index(local_rank, backend, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
 
     def gpus_visible(self):
         return self.torch.cuda.device_count()
+
+    def is_lab_build(self):
+        return bool(getattr(self.native, "IS_LAB_BUILD", False))
 
     def init_process_group(self):
         import torch.distributed as dist
@@ -405,11 +416,11 @@ def run(args, device):
             graph_replay = {"ms_per_step": eg / K * 1e3, "value": whole_job_value(cnt["vox"], world, K, eg) / 1e9,
                             "note": "one hipGraph replay of the same K steps; not the metric"}
 
-    # Extra, NOT the metric (--extras 1): the same K steps with the opt-in backward on the bf16 matrix pipe (every f32 operand
-    # split into three bf16 pieces, six piece products, f32 accumulation: DESIGN 4.3 -- within the 1e-5 contract of the
-    # gradients and deterministic, but not the arithmetic the metric is quoted in, so it stays beside the line).
+    # Extra, NOT the metric (--extras 1, LAB build of the library only -- csrc/Makefile `lab`): the same K steps with the
+    # backward on the bf16 matrix pipe (every f32 operand split into three bf16 pieces: docs/lab_notebook.md 4.3).  The
+    # product library does not contain that kernel (ABI 1.06); the field is null there.
     bf16x3 = None
-    if args.extras and args.impl == 0 and hasattr(device, "bwd_as"):
+    if args.extras and args.impl == 0 and hasattr(device, "bwd_as") and getattr(device, "is_lab_build", lambda: False)():
         def plain_pass(impl):
             """K eager steps between barriers, NO event records between the kernels (seconds, MAX over ranks)."""
             for i in range(min(K, 20)):
@@ -422,20 +433,11 @@ def run(args, device):
                 device.bwd_as(z, impl)
             barrier()
             return max_over_ranks(time.perf_counter() - t0, nred, device.reduce_device())
-        err = None
-        try:
-            device.bwd_as(order[0], 4)                           # does this build / shape have the kernel at all?
-            device.synchronize()
-        except Exception as e:
-            err = f"{type(e).__name__}: {str(e)[:160]}"
-        if max_over_ranks(1.0 if err else 0.0, nred, device.reduce_device()) > 0.0:
-            bf16x3 = {"error": err or "failed on another rank"}
-        else:
-            e0, e4 = plain_pass(0), plain_pass(4)
-            bf16x3 = {"ms_per_step": e4 / K * 1e3, "value": whole_job_value(cnt["vox"], world, K, e4) / 1e9,
-                      "default_same_method": {"ms_per_step": e0 / K * 1e3, "value": whole_job_value(cnt["vox"], world, K, e0) / 1e9},
-                      "note": "K eager steps WITHOUT event records between the kernels, once with the D2T_IMPL_BF16X3 backward (bf16 MFMA, "
-                              "operands split in three) and once with the default backward; neither is the metric"}
+        e0, e4 = plain_pass(0), plain_pass(4)
+        bf16x3 = {"ms_per_step": e4 / K * 1e3, "value": whole_job_value(cnt["vox"], world, K, e4) / 1e9,
+                  "default_same_method": {"ms_per_step": e0 / K * 1e3, "value": whole_job_value(cnt["vox"], world, K, e0) / 1e9},
+                  "note": "lab build: K eager steps WITHOUT event records between the kernels, once with the bf16x3 backward (bf16 MFMA, "
+                          "operands split in three) and once with the default backward; neither is the metric"}
 
     # Extra, NOT the metric (--ops 1, rank 0, a few seconds, after everything that is timed above): every other op / shape
     # of the path -- config 2, the three correlations the model really runs, ROIPool / PSROIPool at config 3 and at the
@@ -521,8 +523,15 @@ def run(args, device):
                                   "the event intervals, which tile event_pass.ms_per_step (asserted); an interval contains one "
                                   "event record (event_pass.event_record_overhead_us = the difference of the two passes per record)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, cnt)
+        if not args.no_cpu_baseline:
+            if world == 1:
+                line["cpu_baseline"] = cpu_baseline(cfg, cnt)
+            else:
+                # N > 1 (north_star: the CPU figure beside the 2 / 4 / 8-GPU lines): rank 0 alone, after everything timed, on its
+                # share of the host's threads and a shorter sample -- the other ranks wait at the closing barrier meanwhile
+                cb = cpu_baseline(cfg, cnt, budget_s=args.cpu_baseline_multi_s, threads=max(1, host_threads() // world))
+                cb["sample"] += f" (rank 0 of {world}, 1/{world} of the host's threads; the per-GPU workload, not the {world}-GPU job)"
+                line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
 
     if dist_on:
@@ -540,8 +549,9 @@ def parse_args(argv=None):
     ap.add_argument("--sets", type=int, default=0, help="rotated buffer sets (0 = enough for > 512 MiB)")
     ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic kernels, 2 tuned only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-multi-s", type=float, default=5.0, help="N > 1: seconds of CPU sample on rank 0 (N = 1 uses ~12 s)")
     ap.add_argument("--graph", type=int, default=1, help="1: also replay the K steps as one HIP graph (reported beside the metric)")
-    ap.add_argument("--extras", type=int, default=1, help="1: also time the K steps with the opt-in bf16x3 backward (reported beside the metric)")
+    ap.add_argument("--extras", type=int, default=1, help="1: with a LAB build of the library also time the K steps with the bf16x3 backward (reported beside the metric)")
     ap.add_argument("--ops", type=int, default=1, help="1: also time every other op / shape of the path (ops[] in the line, rank 0, ~3 s)")
     ap.add_argument("--force-dist", type=int, default=0, help="1: create the process group and run the collectives at world size 1 too "
                     "(launch under torch.distributed.run --nproc-per-node 1)")

@@ -5,6 +5,9 @@
 // environment reads; the only process state is the per-device dynamic-LDS flags of d2t_common.hpp.
 #include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
+#ifdef D2T_LAB_KERNELS
+#include "lab/d2t_lab_selectors.h"
+#endif
 
 using namespace d2t;
 
@@ -39,13 +42,21 @@ int check_pool(const void* fm, const void* rois, const void* out, int R, int C, 
     return D2T_OK;
 }
 
-// D2T_IMPL_MFMA .. D2T_IMPL_BF16X3 demand the tuned kernels (an unsupported shape is an error); AUTO / FAST fall back
-inline bool demands_tuned(int impl) { return impl >= D2T_IMPL_MFMA && impl != D2T_IMPL_FAST; }
-// backward kernel choice of the tuned path: 0 by grid size, 1 the 16-wave strip kernel, 3 bf16x3, 4 strips 8 pixels wide, 5 strips 4 pixels wide
+// The four selectors of include/d2t_ops.h.  Values 3, 4, 6, 7 named lab kernels in ABI 1.05; the product library rejects them
+// since 1.06 -- they exist in the lab build only (make lab: -DD2T_LAB_KERNELS, csrc/lab/d2t_lab_selectors.h).
+#ifdef D2T_LAB_KERNELS
+inline bool impl_ok(int impl) { return impl >= D2T_IMPL_AUTO && impl <= D2T_LAB_IMPL_STRIP4; }
+// backward kernel of the tuned path: 0 the product's, 1 the 16-wave strip kernel, 3 bf16x3, 4 strips 8 pixels wide, 5 strips 4 pixels wide
 inline int bwd_variant_of(int impl)
 {
-    return impl == D2T_IMPL_MFMA_STRIP16 ? 1 : impl == D2T_IMPL_BF16X3 ? 3 : impl == D2T_IMPL_MFMA_WIDE8 ? 4 : impl == D2T_IMPL_MFMA_STRIP4 ? 5 : 0;
+    return impl == D2T_LAB_IMPL_STRIP16 ? 1 : impl == D2T_LAB_IMPL_BF16X3 ? 3 : impl == D2T_LAB_IMPL_WIDE8 ? 4 : impl == D2T_LAB_IMPL_STRIP4 ? 5 : 0;
 }
+#else
+inline bool impl_ok(int impl) { return impl == D2T_IMPL_AUTO || impl == D2T_IMPL_GENERIC || impl == D2T_IMPL_MFMA || impl == D2T_IMPL_FAST; }
+inline int bwd_variant_of(int) { return 0; }
+#endif
+// D2T_IMPL_MFMA (and the lab selectors) demand the tuned kernels (an unsupported shape is an error); AUTO / FAST fall back
+inline bool demands_tuned(int impl) { return impl >= D2T_IMPL_MFMA && impl != D2T_IMPL_FAST; }
 
 inline size_t bins_bytes(int R, int k) { return align_up((size_t)R * k * k * 4 * sizeof(int32_t), 256); }
 
@@ -54,9 +65,14 @@ inline size_t bins_bytes(int R, int k) { return align_up((size_t)R * k * k * 4 *
 extern "C" {
 
 // workspace pointers: 16-byte aligned (the kernels read and write 16-byte vectors and a 64-bit counter in it; any device allocation is)
-static inline bool ws_misaligned(const void* ws) { return (reinterpret_cast<uintptr_t>(ws) & 15u) != 0; }
+static inline bool ws_misaligned_(const void* ws, size_t ws_bytes) { return ws && ws_bytes && (reinterpret_cast<uintptr_t>(ws) & 15u) != 0; }
+#define ws_misaligned(ws) ws_misaligned_(ws, ws_bytes)   /* checked only where a workspace is passed: ws_bytes = 0 never touches it */
 
-int d2t_version(void) { return 105; }   // 1.05: round 4 -- D2T_IMPL_FAST / MFMA_WIDE8 / MFMA_STRIP4, d2t_region_filter_batched_f32, d2t_corr_bwd_levels_workspace_bytes
+int d2t_version(void) { return 106; }   // 1.06: round 5 -- selectors trimmed to AUTO / GENERIC / MFMA / FAST (3, 4, 6, 7 are rejected: lab build only); band-split forward for small grids
+
+#ifdef D2T_LAB_KERNELS
+int d2t_lab_build(void) { return 1; }   // present in the lab build only (csrc/lab/d2t_lab_selectors.h)
+#endif
 
 const char* d2t_error_string(int code)
 {
@@ -86,7 +102,7 @@ size_t d2t_corr_bwd_workspace_bytes(int B, int C, int H, int W, int d, int strid
 int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int d, int stride,
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
@@ -105,7 +121,7 @@ int d2t_corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int 
 int d2t_corr_fwd_f64(const double* fm0, const double* fm1, double* out, int B, int C, int H, int W, int d, int stride,
                      void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, out, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
     if (demands_tuned(impl)) return D2T_EINVAL;
@@ -118,7 +134,7 @@ int d2t_corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, floa
                      int B, int C, int H, int W, int d, int stride,
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
@@ -139,7 +155,7 @@ int d2t_corr_bwd_f64(const double* gout, const double* fm0, const double* fm1, d
                      int B, int C, int H, int W, int d, int stride,
                      void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_corr(fm0, fm1, gout, B, C, H, W, d, stride);
     if (rc != D2T_OK) return rc;
@@ -179,7 +195,7 @@ int d2t_corr_fwd_levels_f32(int n, const float* const* fm0, const float* const* 
                             int B, int H, int W, int d, int stride, int layout, long long bstride,
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)out, C, B, H, W, d, stride, layout, bstride);
     if (rc != D2T_OK) return rc;
@@ -213,7 +229,7 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
                             int B, int H, int W, int d, int stride, int layout, long long bstride,
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_levels(n, (const void* const*)fm0, (const void* const*)fm1, (const void* const*)gout, C, B, H, W, d, stride, layout, bstride);
     if (rc != D2T_OK) return rc;
@@ -225,6 +241,13 @@ int d2t_corr_bwd_levels_f32(int n, const float* const* gout, const float* const*
                                                                      : tuned::CellLayout{cells, 1, 1LL * HW * cells};
     bool tuned_ok = impl != D2T_IMPL_GENERIC;
     for (int l = 0; l < n; ++l) tuned_ok = tuned_ok && tuned::corr_bwd_supported(B, C[l], H, W, d, stride);
+#ifndef D2T_LAB_KERNELS
+    // channel-major gradient: the tuned kernels read a re-laid copy in the caller's workspace; without it the layout-aware anchor runs
+    if (tuned_ok && layout == D2T_LAYOUT_CHANNEL_MAJOR && (!ws || ws_bytes < tuned::corr_bwd_levels_ws_bytes(n, C, B, H, W, lay))) {
+        if (demands_tuned(impl)) return D2T_EWS;
+        tuned_ok = false;
+    }
+#endif
     if (tuned_ok) return tuned::corr_bwd_levels_f32(n, gout, fm0, fm1, gfm0, gfm1, C, B, H, W, lay, as_stream(stream),
                                                     bwd_variant_of(impl), ws, ws ? ws_bytes : 0);
     if (demands_tuned(impl)) return D2T_EINVAL;
@@ -255,7 +278,7 @@ size_t d2t_roipool_bwd_workspace_bytes(int R, int C, int H, int W, int k, int el
 int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_pool(fm, rois, out, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
@@ -273,7 +296,7 @@ int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, i
 int d2t_roipool_fwd_f64(const double* fm, const double* rois, double* out, int R, int C, int H, int W, int k,
                         void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     int rc = check_pool(fm, rois, out, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
     return roipool_fwd_generic<double>(fm, rois, out, R, C, H, W, k, as_stream(stream));
@@ -282,7 +305,7 @@ int d2t_roipool_fwd_f64(const double* fm, const double* rois, double* out, int R
 int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
@@ -299,7 +322,7 @@ int d2t_roipool_bwd_f32(const float* gout, const float* rois, float* gin, int R,
 int d2t_roipool_bwd_f64(const double* gout, const double* rois, double* gin, int R, int C, int H, int W, int k,
                         void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_pool(gin, rois, gout, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
@@ -337,7 +360,7 @@ static int check_ps(const void* fm, const void* rois, const void* out, int R, in
 int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_ps(fm, rois, out, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
@@ -352,7 +375,7 @@ int d2t_psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R,
 int d2t_psroipool_fwd_f64(const double* fm, const double* rois, double* out, int R, int nT, int H, int W, int k,
                           void*, size_t, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     int rc = check_ps(fm, rois, out, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
     return psroipool_fwd_generic<double>(fm, rois, out, R, nT, H, W, k, as_stream(stream));
@@ -361,7 +384,7 @@ int d2t_psroipool_fwd_f64(const double* fm, const double* rois, double* out, int
 int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;
@@ -378,7 +401,7 @@ int d2t_psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int 
 int d2t_psroipool_bwd_f64(const double* gout, const double* rois, double* gin, int R, int nT, int H, int W, int k,
                           void* ws, size_t ws_bytes, int impl, d2t_stream_t stream)
 {
-    if (impl < D2T_IMPL_AUTO || impl > D2T_IMPL_MFMA_STRIP4) return D2T_EINVAL;
+    if (!impl_ok(impl)) return D2T_EINVAL;
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_ps(gin, rois, gout, R, nT, H, W, k);
     if (rc != D2T_OK) return rc;

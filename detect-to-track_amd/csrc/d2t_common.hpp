@@ -111,8 +111,8 @@ inline int ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned lo
     } while (0)
 
 // Developer knobs (environment variables that force one of several measured designs) exist only in harness builds
-// (-DD2T_LAB); the product library reads no environment.
-#ifdef D2T_LAB
+// (-DD2T_LAB, or -DD2T_ENV_KNOBS: the knobs without the in-kernel stamps); the product library reads no environment.
+#if defined(D2T_LAB) || defined(D2T_ENV_KNOBS)
 inline int lab_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 inline const char* lab_env_str(const char* name) { return getenv(name); }
 #else

@@ -103,20 +103,26 @@ static __device__ __attribute__((noinline)) void strip_repair(int role, int lane
     }
 }
 
+// d2t_corr_fwd_band.hip: forward of small grids, a tile's window split over workgroups (bit-identical); cfg 0 = not taken
+int  corr_fwd_band_config(int B, int H, int W);
+int  corr_fwd_band_f32(int cfg, const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, CellLayout lay, hipStream_t st);
+
 // d2t_corr_bwd8.hip
 bool corr_bwd8_supported(int B, int C, int H, int W, int ps, int cs);
 int  corr_bwd8_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
                    int B, int C, int H, int W, hipStream_t st, int variant = 0);
 
-// d2t_corr_bwd8w.hip
+#ifdef D2T_LAB_KERNELS
+// lab/d2t_corr_bwd8w.hip (strips 8 pixels wide x 128 channels: built, measured 81 against 70 us, lost -- notebook R4-3)
 bool corr_bwd8w_supported(int B, int C, int H, int W, int ps, int cs);
 long long corr_bwd8w_workgroups(int B, int C, int W);
 int  corr_bwd8w_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
                     int B, int C, int H, int W, hipStream_t st);
 
-// d2t_corr_bwd8bf.hip
+// lab/d2t_corr_bwd8bf.hip (bf16 matrix pipe, operands split in three: notebook 4.3)
 bool corr_bwd8bf_supported(int B, int C, int H, int W, int ps, int cs);
 int  corr_bwd8bf_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,
                      int B, int C, int H, int W, hipStream_t st);
+#endif
 
 }}  // namespace d2t::tuned

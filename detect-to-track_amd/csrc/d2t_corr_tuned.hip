@@ -910,6 +910,14 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
         hipLaunchKernelGGL(k_corr_fwd_combine, dim3((H * W + CB_PIX - 1) / CB_PIX, B, nl), dim3(256), 0, st, cl, B, H * W, lay);
         return launch_status();
     }
+    // small grids: the tile's WINDOW split over workgroups (d2t_corr_fwd_band.hip), one launch per level
+    if (const int cfg = corr_fwd_band_config(B, H, W)) {
+        for (int l = 0; l < nl; ++l) {
+            const int rc = corr_fwd_band_f32(cfg, fm0[l], fm1[l], out[l], B, C[l], H, W, lay, st);
+            if (rc != D2T_OK) return rc;
+        }
+        return D2T_OK;
+    }
     int order[MAXLV];
     for (int l = 0; l < nl; ++l) order[l] = l;
     for (int a = 0; a < nl; ++a)                     // heaviest first (nl <= 4)
@@ -952,485 +960,22 @@ int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, i
 }
 
 // ====================================================================================
-// Backward.  Both gradients have the same shape of work:
-//     gX[c][t] = sum over window slots w of  G[t][w] * S[c][w]
-// role 0 (gradFM0): t = centre pixels (i,j), S = FM1, slots = the displaced pixels they reach;
-// role 1 (gradFM1): t = displaced pixels (di,dj), S = FM0, slots = the centres that reach them;
-// in both, G = gradOut[b,i,j,di-i+d,dj-j+d] where the reference's loops visit that cell, else 0.
-// This is the gather form of pointwise_correlation_cuda.cu:154-171: no atomics, every output
-// element written exactly once, fixed summation order (bitwise reproducible).
-//
-// Column-strip kernel.  One workgroup owns (role, batch item, a strip 4 pixels wide, 256
-// channels) and walks the strip top to bottom.  The strip's slots are the map rows x 20 columns
-// (5 groups of 4, origin clamped into the map); 4 groups = one k-block = 16 MFMA k-slots, 5
-// k-blocks = one "super-step" = 4 map rows = one tile pitch.  A 4x4 tile u of output pixels
-// interacts with super-steps u-2 .. u+2, so at any time 5 tiles are alive.
-//   MFMA: D[m = 16 channels][n = 16 tile pixels] += A[m][k] * B[k][n].
-//   A: lane (channel m, k-slot g) loads ONE 16-byte piece of S per k-block (group 4*kb+g); its
-//      4 floats are the A operands of the block's 4 MFMAs -- and of all 5 live tiles, so every
-//      byte of S is fetched once per strip instead of once per tile (~5x less L2 traffic than a
-//      tile-per-workgroup layout, which measured L2-bound).
-//   B: G fragments [k-block][live tile][lane][4] of a whole super-step are produced cooperatively
-//      (6-7 elements per thread, read straight from gradOut, zero where the reference's loops do
-//      not go) into a double-buffered LDS ring, one workgroup barrier per super-step; each wave
-//      reads them back with ds_read_b128.  Waves drift apart inside a super-step, so one wave's
-//      index arithmetic overlaps another wave's MFMAs.
-// A wave owns one c-tile (16 channels): 1 load + 5 LDS reads feed 20 MFMAs per k-block; 16 waves
-// share the ring.  After super-step s tile s-2 is complete: it is stored and the 5 accumulators
-// rotate.  At B=8, C=256, 38x63 the grid is 2 x 8 x 16 = 256 workgroups: one per CU.
+// Backward.  The product's tuned backward is the 8-wave column-strip kernel of d2t_corr_bwd8.hip (reference layout; the
+// channel-major gradient of the tracker's concat buffer is re-laid into the caller's workspace first).  The round-2 16-wave
+// strip kernels live in lab/d2t_corr_bwd16.inc and are compiled into the lab build only.
 // ====================================================================================
-constexpr int ST_WAVES = 16;
-constexpr int ST_THREADS = ST_WAVES * 64;
-constexpr int ST_CH = ST_WAVES * 16;                // channels per workgroup pass
-// (1600 of the 2048 quad slots of a super-step are real: 5 k-blocks x 5 tiles x 64 lanes)
-constexpr int Q_PER_THREAD = 2;                     // every thread produces 2 quads: 2048 slots, 448 unused
-constexpr int RING_SS = Q_PER_THREAD * ST_THREADS * 4;   // 8192 floats = 32 KB per buffer
-
-// Descriptor of one G-ring quad (k-block q of a super-step, live tile a, lane l): four
-// consecutive columns s = 0..3 of one (tile pixel, slot group) pair.  Everything that does not
-// depend on the super-step is folded into it once per workgroup:
-//   the quad reads gradOut[off0 + ss*step + dp*s] for the s whose bit is set in `mask`, provided
-//   lo <= ss < hi (tile row exists, tile pixel and slot row inside the map); otherwise exact 0.
-// role 0: the four cells are adjacent in one gradOut row (dp = cs); role 1: they sit in four
-// adjacent centre pixels, one cell to the left each time (dp = ps - cs).  (ps, cs): CellLayout.
-struct QuadDesc { int off0, lo, hi, mask; };
-
-__device__ __forceinline__ QuadDesc strip_quad_desc(int role, int e, int H, int W, int tiles_i, int j0, int col0, int ps, int cs)
-{
-    const int q = e / (NACT * 64), r = e - q * (NACT * 64);
-    const int a = r >> 6, l = r & 63, t = l & 15, gg = l >> 4;
-    const int x = 4 * q + gg, xr = (x * 13) >> 6, cg = x - xr * NCG;      // x / 5, x % 5 (x < 32)
-    const int tpi = t >> 2, tj = j0 + (t & 3), sj = col0 + 4 * cg;
-    // at super-step ss: tile row u = ss-2+a, tile pixel row ti = 4u+tpi, slot row rho = 4ss+xr
-    const int ci = role ? 4 * a + tpi - xr : xr - 4 * a - tpi + 2 * DT;    // displaced - centre + d (constant)
-    const int cj = role ? tj - sj + DT : sj - tj + DT;                     // for s = 0; role 0: +s, role 1: -s
-    const int dc = role ? -1 : 1;
-    QuadDesc d;
-    d.mask = 0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) d.mask |= (cj + dc * s >= 0 && cj + dc * s < 2 * DT) ? (1 << s) : 0;
-    if (ci < 0 || ci >= 2 * DT || tj >= W || q >= KB_SS) d.mask = 0;
-    // centre pixel at ss = 0 (may be negative: only dereferenced when lo <= ss)
-    const int pix0 = role ? xr * W + sj : (4 * (a - 2) + tpi) * W + tj;
-    d.off0 = pix0 * ps + (ci * CW + cj) * cs;
-    // validity window in ss: 0 <= u < tiles_i, ti < H, rho < H
-    int lo = 2 - a, hi = tiles_i + 2 - a;
-    const int hi_t = (H - tpi + 3) / 4 + 2 - a;                            // 4(ss-2+a)+tpi < H
-    const int hi_r = (H - xr + 3) / 4;                                     // 4ss+xr < H
-    hi = hi < hi_t ? hi : hi_t;
-    hi = hi < hi_r ? hi : hi_r;
-    d.lo = lo < 0 ? 0 : lo;
-    d.hi = hi;
-    return d;
-}
-
-__device__ __forceinline__ f32x4 strip_quad_load(const float* __restrict__ gb, const QuadDesc& d, int ss,
-                                                 int step, int dp)
-{
-    const bool in = ss >= d.lo && ss < d.hi;
-    const int base = d.off0 + ss * step;
-    f32x4 v;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {                                          // branch-free: unused -> gb[0] -> 0
-        const bool use = in && ((d.mask >> s) & 1);
-        const float x_ = gb[use ? base + dp * s : 0];
-        v[s] = use ? x_ : 0.f;
-    }
-    return v;
-}
-
-
-// The same ring quads fetched with ONE 16-byte load each (reference layout only: cs = 1, the 17 cells
-// of a gradOut row are contiguous).  The dword form above costs the texture-address unit four
-// instructions per quad, each touching 64 scattered lines; issued by all 16 waves at the end of a
-// super-step they form a burst the next super-step's FM loads queue behind (rocprofv3: TA busy 42 % +
-// MFMA busy 52 % ~ the whole kernel, i.e. the two phases alternate instead of overlapping).
-//   role 0: the quad IS four adjacent cells (cj .. cj+3) of one centre pixel's row.
-//   role 1: a quad's four values sit in four different centre pixels (stride ps - 1); the contiguous
-//     direction is the TILE COLUMN: for one centre pixel (slot row xr, column sj + s) the tile pixels
-//     (tpi, 0..3) read cells cj0 .. cj0+3.  So a role-1 thread fetches a "unit" (k-block q, live tile
-//     a, slot group gg, tile row tpi, slot column s) and scatters its four values to component s of the
-//     quads of lanes (tpi*4 + 0..3, gg): four ds_write_b32 instead of one ds_write_b128.
-// A run that starts left of cell 0 (cj < 0: those cells are outside the reference's loops) is fetched
-// from cell 0 and shifted right by `sh` components, so no address below the pixel's row is formed.
-// mask: bit c = component c carries a visited cell; bits 4-5 = sh.
-__device__ __forceinline__ QuadDesc strip_vec_desc(int role, int e, int H, int W, int tiles_i, int j0, int col0, int ps)
-{
-    const int q = e / (NACT * 64), r = e - q * (NACT * 64);
-    const int a = r >> 6, l = r & 63, gg = l >> 4;
-    const int x = 4 * q + gg, xr = (x * 13) >> 6, cg = x - xr * NCG;      // x / 5, x % 5 (x < 32)
-    const int tpi = (l >> 2) & 3, lo2 = l & 3;                             // role 0: lo2 = tile column; role 1: slot column s
-    const int ci = role ? 4 * a + tpi - xr : xr - 4 * a - tpi + 2 * DT;    // displaced - centre + d (constant)
-    // first cell of the run, and which tile columns / centre columns exist
-    const int tj = j0 + lo2, sj = col0 + 4 * cg + (role ? lo2 : 0);
-    const int cj = role ? j0 - sj + DT : sj - tj + DT;                     // component c reads cell cj + c
-    int mask = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const bool col_ok = role ? j0 + c < W : tj < W;
-        mask |= (cj + c >= 0 && cj + c < 2 * DT && col_ok) ? (1 << c) : 0;
-    }
-    if (ci < 0 || ci >= 2 * DT || q >= KB_SS) mask = 0;
-    const int sh = mask && cj < 0 ? -cj : 0;                               // 0..3
-    const int pix0 = role ? xr * W + sj : (4 * (a - 2) + tpi) * W + tj;    // centre pixel at ss = 0
-    QuadDesc d;
-    d.off0 = pix0 * ps + ci * CW + cj + sh;
-    d.mask = mask | (sh << 4);
-    int lo = 2 - a, hi = tiles_i + 2 - a;
-    const int hi_t = (H - tpi + 3) / 4 + 2 - a;                            // 4(ss-2+a)+tpi < H
-    const int hi_r = (H - xr + 3) / 4;                                     // 4ss+xr < H
-    hi = hi < hi_t ? hi : hi_t;
-    hi = hi < hi_r ? hi : hi_r;
-    d.lo = lo < 0 ? 0 : lo;
-    d.hi = hi;
-    return d;
-}
-
-__device__ __forceinline__ f32x4 strip_vec_load(const float* __restrict__ gb, const QuadDesc& d, int ss, int step)
-{
-    const bool in = ss >= d.lo && ss < d.hi && (d.mask & 15);
-    const f32x4 v = *reinterpret_cast<const f32x4u*>(gb + (unsigned)(in ? d.off0 + ss * step : 0));
-    // shift right by sh (components below sh are unvisited cells: masked off)
-    const bool s1 = d.mask & 16, s2 = d.mask & 32;
-    const float t1 = s1 ? v[0] : v[1], t2 = s1 ? v[1] : v[2], t3 = s1 ? v[2] : v[3];
-    const float u2 = s2 ? v[0] : t2, u3 = s2 ? t1 : t3;
-    f32x4 o;
-    o[0] = in && (d.mask & 1) ? v[0] : 0.f;
-    o[1] = in && (d.mask & 2) ? t1 : 0.f;
-    o[2] = in && (d.mask & 4) ? u2 : 0.f;
-    o[3] = in && (d.mask & 8) ? u3 : 0.f;
-    return o;
-}
-
-// where a thread's quad / unit goes in the ring (floats).  role 0: its own quad e.  role 1: component
-// lo2 = s of the quads of lanes (tpi*4 + c, gg), c = 0..3 -- 4 floats apart.
-__device__ __forceinline__ void strip_vec_put(float* __restrict__ rb, int role, int e, const f32x4& v)
-{
-    if (!role) { reinterpret_cast<f32x4*>(rb)[e] = v; return; }
-    const int l = e & 63;
-    float* w = rb + (((e & ~63) + (l & 0x3c)) << 2) + (l & 3);             // quad (q, a, lane (tpi*4 + 0, gg)), component s
-    w[0] = v[0]; w[4] = v[1]; w[8] = v[2]; w[12] = v[3];
-}
-
-// (non-finite inputs: strip_repair, d2t_corr_common.hpp)
-template <bool VEC>                                              // VEC: 16-byte gradOut loads (reference layout)
-__global__ void __launch_bounds__(ST_THREADS)
-k_corr_bwd_strip(const float* __restrict__ gout, const float* __restrict__ fm0, const float* __restrict__ fm1,
-                 float* __restrict__ g0, float* __restrict__ g1,
-                 int B, int C, int H, int W, int tiles_i, int tiles_j, CellLayout lay)
-{
-    __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 64 KB
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    D2T_WCLK_DECL(w_t0, w_t1, w_t2, w_t3, w_a, w_b, w_c, w_d, w_q = 0, w_put = 0, w_bar = 0, w_st = 0);
-    D2T_WCLK(w_t0);
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);                // both roles of a batch item stay on one XCD: they share gradOut[b]
-    const int tj = bid % tiles_j, role = (bid / tiles_j) & 1, b = bid / (2 * tiles_j);
-    const int j0 = tj * TP, HW = H * W;
-    const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
-    const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
-    const float* S = role ? fm0 : fm1;
-    float* gx = role ? g1 : g0;
-    const float* gb = gout + (size_t)b * lay.bs;
-
-    const int cw = blockIdx.y * ST_CH + wave * 16;                   // first channel of this wave's c-tile
-    const int cl = cw + n < C ? cw + n : C - 1;                      // lane's channel (clamped; never stored)
-    const float* sp = S + ((size_t)b * C + cl) * HW + col0;
-
-    f32x4 acc[NACT];
-#pragma unroll
-    for (int a = 0; a < NACT; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // S fragment of k-block 5*ss + q: group 20*ss + 4q + g.  Rows past the map carry G = 0.
-    auto s_load = [&](int ss, int q) -> f32x4 {
-        const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
-        int rho = 4 * ss + xr;
-        rho = rho < H ? rho : H - 1;
-        if (D2T_ABL & 8) rho = 0;                                    // (lab: every k-block re-reads map row 0 -- same instructions, ~10x fewer distinct lines)
-        return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
-    };
-    unsigned long long badt = 0;                                     // tiles this lane stored a non-finite value for (bit u mod 64)
-    auto store_tile = [&](const f32x4& d, int u) {
-        const int i = 4 * u + (n >> 2), j = j0 + (n & 3);
-        if (u < 0 || u >= tiles_i || i >= H || j >= W) return;
-        badt |= nonfinite4(d) ? 1ull << (u & 63) : 0ull;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = cw + 4 * g + r;
-            if (c < C) gx[((size_t)b * C + c) * HW + i * W + j] = d[r];
-        }
-    };
-    // the two ring quads this thread produces every super-step (slots >= 1600 are padding: mask 0)
-    const QuadDesc qd0 = VEC ? strip_vec_desc(role, tid, H, W, tiles_i, j0, col0, lay.ps)
-                             : strip_quad_desc(role, tid, H, W, tiles_i, j0, col0, lay.ps, lay.cs);
-    const QuadDesc qd1 = VEC ? strip_vec_desc(role, tid + ST_THREADS, H, W, tiles_i, j0, col0, lay.ps)
-                             : strip_quad_desc(role, tid + ST_THREADS, H, W, tiles_i, j0, col0, lay.ps, lay.cs);
-    const int gstep = 4 * W * lay.ps;                                 // gradOut offset of 4 map rows
-    const int gdp = role ? lay.ps - lay.cs : lay.cs;
-    auto g_load = [&](const QuadDesc& d, int ss) -> f32x4 {
-        if constexpr (VEC) return strip_vec_load(gb, d, ss, gstep);
-        else return strip_quad_load(gb, d, ss, gstep, gdp);
-    };
-    auto g_put = [&](float* rb, int e, const f32x4& v) {
-        if constexpr (VEC) strip_vec_put(rb, role, e, v);
-        else reinterpret_cast<f32x4*>(rb)[e] = v;
-    };
-
-    // prologue: ring[0] <- super-step 0, registers <- super-step 1
-    g_put(ring[0], tid, g_load(qd0, 0));
-    g_put(ring[0], tid + ST_THREADS, g_load(qd1, 0));
-    f32x4 gn0 = g_load(qd0, 1);
-    f32x4 gn1 = g_load(qd1, 1);
-    f32x4 av = s_load(0, 0);
-    __syncthreads();
-    D2T_WCLK(w_t1);
-    D2T_LAB_ONLY(w_d = w_t1;)
-
-    // The super-step body is straight-line code (no branches): every load is unconditional, so the
-    // compiler can retire them with counted s_waitcnt instead of draining at block boundaries.
-    // LO/HI: the live accumulators [LO, HI) of this super-step -- the first two super-steps carry
-    // tiles -2/-1 in acc[0..1], the last two carry tiles past the map in acc[3..4]; their MFMAs
-    // (12 % of the strip at 38 rows) are never stored and are not issued.
-    auto super_step = [&](int ss, auto lo_c, auto hi_c) {
-        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        const int cur = ss & 1;
-        const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
-#pragma unroll
-        for (int q = 0; q < KB_SS; ++q) {
-            const f32x4 a4 = av;
-            if (!(D2T_ABL & 4)) av = q + 1 < KB_SS ? s_load(ss, q + 1) : s_load(ss + 1, 0);
-            f32x4 bv[NACT];
-#pragma unroll
-            for (int a = LO; a < HI; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
-            // One k-block of a tile's 25 is structurally zero (4 % of the MFMAs): for role 0 the last one of
-            // its oldest live tile (slot row 4*ss+3 lies below every window that ends in this super-step),
-            // for role 1 the first one of its newest (slot row 4*ss lies above every window that starts
-            // here).  Those four MFMAs go behind a wave-uniform branch.
-            const int A0 = (q == KB_SS - 1 && LO == 0) ? 1 : LO;                 // without the role-0 dead block
-            const int A1 = (q == 0 && HI == NACT) ? NACT - 1 : HI;               // without the role-1 dead block
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {                            // s outer: independent accumulators
-#pragma unroll
-                for (int a = A0; a < A1; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
-            }
-            if (A0 != LO && role) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[LO] = D2T_MFMA(a4[s], bv[LO][s], acc[LO]);
-            }
-            if (A1 != HI && !role) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[HI - 1] = D2T_MFMA(a4[s], bv[HI - 1][s], acc[HI - 1]);
-            }
-        }
-        // hand super-step ss+1's G (requested a whole super-step ago) to the other buffer, then
-        // request ss+2's: these loads are the YOUNGEST in the queue, so no FM load of the next
-        // super-step has to wait behind them (vmcnt retires in order)
-        D2T_WCLK(w_a);
-        g_put(ring[cur ^ 1], tid, gn0);
-        g_put(ring[cur ^ 1], tid + ST_THREADS, gn1);
-        if (!(D2T_ABL & 1)) {
-            gn0 = g_load(qd0, ss + 2);                               // past the map: all zeros
-            gn1 = g_load(qd1, ss + 2);
-        }
-        D2T_WCLK(w_b);
-        __syncthreads();
-        D2T_WCLK(w_c);
-        if (!(D2T_ABL & 2)) store_tile(acc[0], ss - 2);              // complete after its 5th super-step
-        else asm volatile("" ::"v"(acc[0]));                         // (lab: keep the MFMAs alive without the stores)
-#pragma unroll
-        for (int a = 0; a + 1 < NACT; ++a) acc[a] = acc[a + 1];
-        acc[NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        D2T_LAB_ONLY(w_q += w_a - w_d; w_put += w_b - w_a; w_bar += w_c - w_b;)
-        D2T_WCLK(w_d);
-        D2T_LAB_ONLY(w_st += w_d - w_c;)
-    };
-    using std::integral_constant;
-    if (tiles_i >= 4) {
-        super_step(0, integral_constant<int, 2>{}, integral_constant<int, NACT>{});
-        super_step(1, integral_constant<int, 1>{}, integral_constant<int, NACT>{});
-        for (int ss = 2; ss < tiles_i - 2; ++ss) super_step(ss, integral_constant<int, 0>{}, integral_constant<int, NACT>{});
-        super_step(tiles_i - 2, integral_constant<int, 0>{}, integral_constant<int, NACT - 1>{});
-        super_step(tiles_i - 1, integral_constant<int, 0>{}, integral_constant<int, NACT - 2>{});
-    } else {
-        for (int ss = 0; ss < tiles_i; ++ss) super_step(ss, integral_constant<int, 0>{}, integral_constant<int, NACT>{});
-    }
-    D2T_WCLK(w_t2);
-    store_tile(acc[0], tiles_i - 2);                                 // their remaining super-steps lie below the map
-    store_tile(acc[1], tiles_i - 1);
-#ifdef D2T_LAB
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    D2T_WCLK(w_t3);
-    if (lane == 0) {
-        unsigned long long* o = lab_wave_stamps + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * ST_WAVES + wave) * 8;
-        o[0] = w_t0; o[1] = w_t1; o[2] = w_t2; o[3] = w_t3; o[4] = w_q; o[5] = w_put; o[6] = w_bar; o[7] = w_st;
-    }
+#ifdef D2T_LAB_KERNELS
+#include "lab/d2t_corr_bwd16.inc"
 #endif
-    if (__builtin_expect(__any(badt != 0), 0)) {                     // cold: non-finite inputs only
-        unsigned lo = (unsigned)badt, hi = (unsigned)(badt >> 32);
-#pragma unroll
-        for (int off = 32; off; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
-        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-        if (tiles_i > 64) {
-            strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs, 0, H);
-        } else {
-            for (int u = 0; u < tiles_i; ++u)
-                if ((m >> u) & 1)
-                    strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs,
-                                 4 * u, 4 * u + 4 < H ? 4 * u + 4 : H);
-        }
-    }
-}
 
-// The same kernel with the workgroup width as a template parameter (instantiated for 4 waves = 64
-// channels), used when 16-wave workgroups would leave most CUs idle (B = 1 shapes of the real
-// model).  Kept separate from the 16-wave kernel above, whose code generation it perturbs (+6 %).
-template <int ST_WAVES, int PROD_WAVES>                          // MFMA waves (16 channels each) + waves that only produce G
-__global__ void __launch_bounds__((ST_WAVES + PROD_WAVES) * 64)
-k_corr_bwd_strip_n(BwdLevels lv, int B, int H, int W, int tiles_i, int tiles_j, CellLayout lay)
-{
-    // logical id (XCD-aware over the WHOLE grid: every XCD gets a contiguous run of the logical order, i.e. strips of the
-    // same channel block, which share the rows of S), then the level of this workgroup and (strip, channel block) inside
-    // it (wave-uniform)
-    const int gl = xcd_remap(blockIdx.x, gridDim.x);
-    int L = 0, wg0 = 0;
-#pragma unroll
-    for (int l = 1; l < MAXLV; ++l)
-        if (l < lv.n && gl >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
-    const float* __restrict__ gout = lv.gout[0];
-    const float* __restrict__ fm0 = lv.fm0[0];
-    const float* __restrict__ fm1 = lv.fm1[0];
-    float* __restrict__ g0 = lv.g0[0];
-    float* __restrict__ g1 = lv.g1[0];
-    int C = lv.C[0];
-#pragma unroll
-    for (int l = 1; l < MAXLV; ++l)
-        if (L == l) { gout = lv.gout[l]; fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; g0 = lv.g0[l]; g1 = lv.g1[l]; C = lv.C[l]; }
-    const int nstrips = 2 * B * tiles_j, lid = gl - wg0;
-    const int blk_x = lid % nstrips, blk_y = lid / nstrips;
-    constexpr int ST_THREADS = (ST_WAVES + PROD_WAVES) * 64;
-    constexpr int ST_CH = ST_WAVES * 16;                             // channels per workgroup pass
-    constexpr int Q_PER_THREAD = 2048 / ST_THREADS;                  // ring quads per thread (2 or 8)
-    __shared__ __attribute__((aligned(16))) float ring[2][RING_SS];  // 64 KB
-
-    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool mfma_wave = PROD_WAVES == 0 || wave < ST_WAVES;       // wave-uniform
-    const int bid = blk_x;
-    const int tj = bid % tiles_j, b = (bid / tiles_j) % B, role = bid / (tiles_j * B);
-    const int j0 = tj * TP, HW = H * W;
-    const int wleft = j0 - DT + role;                                // role 1 window is shifted by one
-    const int col0 = wleft < 0 ? 0 : (wleft > W - WC ? W - WC : wleft);
-    const float* S = role ? fm0 : fm1;
-    float* gx = role ? g1 : g0;
-    const float* gb = gout + (size_t)b * lay.bs;
-
-    const int cw = blk_y * ST_CH + (mfma_wave ? wave : 0) * 16;                   // first channel of this wave's c-tile
-    const int cl = cw + n < C ? cw + n : C - 1;                      // lane's channel (clamped; never stored)
-    const float* sp = S + ((size_t)b * C + cl) * HW + col0;
-
-    f32x4 acc[NACT];
-#pragma unroll
-    for (int a = 0; a < NACT; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // S fragment of k-block 5*ss + q: group 20*ss + 4q + g.  Rows past the map carry G = 0.
-    auto s_load = [&](int ss, int q) -> f32x4 {
-        const int x = 4 * q + g, xr = (x * 13) >> 6, cg = x - xr * NCG;
-        int rho = 4 * ss + xr;
-        rho = rho < H ? rho : H - 1;
-        return *reinterpret_cast<const f32x4u*>(sp + rho * W + 4 * cg);
-    };
-    bool bad = false;                                                // this lane stored a non-finite value
-    auto store_tile = [&](const f32x4& d, int u) {
-        const int i = 4 * u + (n >> 2), j = j0 + (n & 3);
-        if (u < 0 || u >= tiles_i || i >= H || j >= W) return;
-        bad = bad || nonfinite4(d);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = cw + 4 * g + r;
-            if (c < C) gx[((size_t)b * C + c) * HW + i * W + j] = d[r];
-        }
-    };
-    // the two ring quads this thread produces every super-step (slots >= 1600 are padding: mask 0)
-    QuadDesc qd[Q_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < Q_PER_THREAD; ++k) qd[k] = strip_quad_desc(role, tid + k * ST_THREADS, H, W, tiles_i, j0, col0, lay.ps, lay.cs);
-    const int gstep = 4 * W * lay.ps;                                 // gradOut offset of 4 map rows
-    const int gdp = role ? lay.ps - lay.cs : lay.cs;
-
-    // prologue: ring[0] <- super-step 0, registers <- super-step 1
-    f32x4 gn[Q_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < Q_PER_THREAD; ++k)
-        reinterpret_cast<f32x4*>(ring[0])[tid + k * ST_THREADS] = strip_quad_load(gb, qd[k], 0, gstep, gdp);
-#pragma unroll
-    for (int k = 0; k < Q_PER_THREAD; ++k) gn[k] = strip_quad_load(gb, qd[k], 1, gstep, gdp);
-    f32x4 av = s_load(0, 0);
-    __syncthreads();
-
-    // The loop body is straight-line code (no branches): every load is unconditional, so the
-    // compiler can retire them with counted s_waitcnt instead of draining at block boundaries.
-    for (int ss = 0; ss < tiles_i; ++ss) {
-        const int cur = ss & 1;
-        const f32x4* rb = reinterpret_cast<const f32x4*>(ring[cur]);
-        if (mfma_wave) {
-#pragma unroll
-        for (int q = 0; q < KB_SS; ++q) {
-            const f32x4 a4 = av;
-            av = q + 1 < KB_SS ? s_load(ss, q + 1) : s_load(ss + 1, 0);
-            f32x4 bv[NACT];
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) bv[a] = rb[(q * NACT + a) * 64 + lane];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {                            // s outer: 5 independent accumulators
-#pragma unroll
-                for (int a = 0; a < NACT; ++a) acc[a] = D2T_MFMA(a4[s], bv[a][s], acc[a]);
-            }
-        }
-        }
-        // hand super-step ss+1's G (requested a whole super-step ago) to the other buffer, then
-        // request ss+2's: these loads are the YOUNGEST in the queue, so no FM load of the next
-        // super-step has to wait behind them (vmcnt retires in order)
-#pragma unroll
-        for (int k = 0; k < Q_PER_THREAD; ++k) reinterpret_cast<f32x4*>(ring[cur ^ 1])[tid + k * ST_THREADS] = gn[k];
-#pragma unroll
-        for (int k = 0; k < Q_PER_THREAD; ++k) gn[k] = strip_quad_load(gb, qd[k], ss + 2, gstep, gdp);   // past the map: zeros
-        __syncthreads();
-        if (mfma_wave) store_tile(acc[0], ss - 2);                   // complete after its 5th super-step
-#pragma unroll
-        for (int a = 0; a + 1 < NACT; ++a) acc[a] = acc[a + 1];
-        acc[NACT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (mfma_wave) {
-        store_tile(acc[0], tiles_i - 2);                             // their remaining super-steps lie below the map
-        store_tile(acc[1], tiles_i - 1);
-        if (__builtin_expect(__any(bad), 0))                         // cold: non-finite inputs only
-            strip_repair(role, lane, gb, S + (size_t)b * C * HW, gx + (size_t)b * C * HW, cw, C, H, W, j0, lay.ps, lay.cs, 0, H);
-    }
-}
-
+// The tuned backward = the 8-wave strip kernel: d_max 8, stride 1, maps at least 17 rows high (five 4-row tiles alive at a time).
+// Everything else (and f64) is the second tier's business (d2t_corr_blocked.hip), bit-identical to the anchor kernels.
 bool corr_bwd_supported(int B, int C, int H, int W, int d, int s)
 {
-    if (d != DT || s != 1 || B < 1 || C < 1 || H < 1 || W < WC) return false;
-    const long long blocks = 2LL * B * ((W + TP - 1) / TP);
-    return blocks * ((C + 63) / 64) <= 0x7fffffffLL;
+    return d == DT && s == 1 && H >= 1 && corr_bwd8_supported(B, C, H, W, CELLS, 1);
 }
 
 size_t corr_bwd_ws_bytes(int, int, int, int, int, int) { return 0; }
-
-#ifndef D2T_BWD_WIDE_DEFAULT
-#define D2T_BWD_WIDE_DEFAULT 0
-#endif
-
-// nl problems of one spatial shape.  Reference layout: every level is launched by itself with the 8-wave kernel of
-// d2t_corr_bwd8.hip (channel blocks sized to the grid).  Channel-major layout, maps shorter than 17 rows, or on request:
-// a level whose 256-channel grid fills at least 100 CUs takes k_corr_bwd_strip, the remaining levels share ONE launch
-// of the 4-wave kernel, heaviest first.
-// Default choice between the two 8-wave kernels (both reference layout): strips 8 pixels wide need their grid
-// (2 B ceil(W/8) ceil(C/128) workgroups) to fill the chip; the 4-pixel kernel sizes its channel blocks to any grid.
-static bool corr_bwd_prefers_wide(int B, int C, int W)
-{
-    return D2T_BWD_WIDE_DEFAULT && corr_bwd8w_workgroups(B, C, W) >= 224;
-}
 
 // The channel-major gradient of the tracker's concat buffer, one level: cell c of pixel p of item b at gout[b*bs + c*HW + p].  The
 // 8-wave strip kernels read gradOut in the reference's layout ((2d+1)^2 contiguous cells per pixel); for this layout the levels call
@@ -1474,11 +1019,22 @@ size_t corr_bwd_levels_ws_bytes(int nl, const int* C, int B, int H, int W, CellL
     return (size_t)nl * B * H * W * CELLS * sizeof(float);
 }
 
+// nl problems of one spatial shape, every level launched by itself with the 8-wave kernel (channel blocks sized to the grid).
+// Channel-major layout: needs the workspace of corr_bwd_levels_ws_bytes (the C ABI falls back to the layout-aware anchor kernel
+// without it).  bwd_variant: 0 = the product's choice; the lab build (-DD2T_LAB_KERNELS) adds 1 = 16-wave strip kernel,
+// 3 = bf16x3, 4 = strips 8 pixels wide, 5 = strips 4 pixels wide demanded.
 int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm0, const float* const* fm1,
                         float* const* g0, float* const* g1, const int* C, int B, int H, int W, CellLayout lay, hipStream_t st,
                         int bwd_variant, void* ws, size_t ws_bytes)
 {
-    const size_t relay = bwd_variant != 1 ? corr_bwd_levels_ws_bytes(nl, C, B, H, W, lay) : 0;
+#ifndef D2T_LAB_KERNELS
+    (void)bwd_variant;
+#endif
+    const size_t relay =
+#ifdef D2T_LAB_KERNELS
+        bwd_variant == 1 ? 0 :
+#endif
+        corr_bwd_levels_ws_bytes(nl, C, B, H, W, lay);
     if (relay && ws && ws_bytes >= relay) {                           // channel-major gradient: re-lay, then the reference-layout kernels
         RelayLevels rl;
         const float* gref[MAXLV];
@@ -1495,6 +1051,7 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
         const CellLayout ref{CELLS, 1, 1LL * H * W * CELLS};
         return corr_bwd_levels_f32(nl, gref, fm0, fm1, g0, g1, C, B, H, W, ref, st, bwd_variant, nullptr, 0);
     }
+#ifdef D2T_LAB_KERNELS
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     int small[MAXLV], ns = 0;
     for (int l = 0; l < nl; ++l) {
@@ -1502,12 +1059,11 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
         if (bwd_variant == 3 && corr_bwd8bf_supported(B, C[l], H, W, lay.ps, lay.cs)) {  // bf16 matrix pipe, operands split in three
             const int rc = corr_bwd8bf_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st);
             if (rc != D2T_OK) return rc;
-        } else if (bwd_variant != 1 && bwd_variant != 5 && corr_bwd8w_supported(B, C[l], H, W, lay.ps, lay.cs) &&
-                   (bwd_variant == 4 || corr_bwd_prefers_wide(B, C[l], W))) {            // strips 8 pixels wide x 128 channels
+        } else if (bwd_variant == 4 && corr_bwd8w_supported(B, C[l], H, W, lay.ps, lay.cs)) {   // strips 8 pixels wide x 128 channels
             const int rc = corr_bwd8w_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st);
             if (rc != D2T_OK) return rc;
-        } else if (bwd_variant != 1 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {   // any grid: the kernel cuts the channels to fit it
-            const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st, bwd_variant == 2 ? 1 : 0);
+        } else if (bwd_variant != 1 && corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) {
+            const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st, 0);
             if (rc != D2T_OK) return rc;
         } else if (wide >= 100 && lay.cs == 1)
             hipLaunchKernelGGL(k_corr_bwd_strip<true>, dim3(2 * B * tiles_j, (C[l] + ST_CH - 1) / ST_CH), dim3(ST_THREADS), 0, st,
@@ -1537,6 +1093,15 @@ int corr_bwd_levels_f32(int nl, const float* const* gout, const float* const* fm
     else                                                             // small grids: 4 waves (64 channels) per workgroup
         hipLaunchKernelGGL((k_corr_bwd_strip_n<4, 0>), dim3(end), dim3(256), 0, st, lv, B, H, W, tiles_i, tiles_j, lay);
     return launch_status();
+#else
+    if (lay.cs != 1) return D2T_EWS;                                  // channel-major without its workspace: the C ABI does not get here
+    for (int l = 0; l < nl; ++l) {
+        if (!corr_bwd8_supported(B, C[l], H, W, lay.ps, lay.cs)) return D2T_EINVAL;
+        const int rc = corr_bwd8_f32(gout[l], fm0[l], fm1[l], g0[l], g1[l], B, C[l], H, W, st, 0);
+        if (rc != D2T_OK) return rc;
+    }
+    return D2T_OK;
+#endif
 }
 
 int corr_bwd_f32(const float* gout, const float* fm0, const float* fm1, float* g0, float* g1,

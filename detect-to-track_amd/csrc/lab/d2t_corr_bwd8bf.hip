@@ -25,7 +25,7 @@
 // Non-finite inputs: a piece of Inf / NaN is NaN, the tile's accumulators become non-finite and the wave repairs its
 // region in the reference's form (strip_repair), as in the f32 kernels.  Finite values above the bf16 range (> 3.39e38)
 // take that path too.
-#include "d2t_corr_common.hpp"
+#include "../d2t_corr_common.hpp"
 #include <type_traits>
 
 namespace d2t { namespace tuned {

@@ -24,7 +24,7 @@
 // enumeration with G = 0 (their S operand is whatever lies there -- the neighbouring row, or the range check's
 // zeros); a non-finite value there is caught by the same repair path as any other (d2t_corr_common.hpp).  A piece
 // that straddles the END of the last channel's last row keeps its in-range dwords (per-dword range check).
-#include "d2t_corr_common.hpp"
+#include "../d2t_corr_common.hpp"
 #include <type_traits>
 
 namespace d2t { namespace tuned {

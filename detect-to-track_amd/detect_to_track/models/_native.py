@@ -21,7 +21,10 @@ _HERE = Path(__file__).resolve().parent
 _LIB_ENV = "D2T_OPS_LIBRARY"
 _DEFAULT = _HERE.parent.parent / "lib" / "libd2t_ops.so"
 
-IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_MFMA_STRIP16, IMPL_BF16X3, IMPL_FAST, IMPL_MFMA_WIDE8, IMPL_MFMA_STRIP4 = range(8)
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_FAST = 0, 1, 2, 5       # include/d2t_ops.h
+# selectors of the LAB build only (csrc/lab/d2t_lab_selectors.h; `make -C csrc lab`, D2T_OPS_LIBRARY=.../lib_lab/libd2t_ops.so):
+# the product library rejects them with D2T_EINVAL
+LAB_IMPL_STRIP16, LAB_IMPL_BF16X3, LAB_IMPL_WIDE8, LAB_IMPL_STRIP4 = 3, 4, 6, 7
 
 
 def _locate() -> Path:
@@ -92,6 +95,8 @@ SYMBOLS += ["d2t_region_filter_workspace_bytes", "d2t_region_filter_f32", "d2t_r
 _proto("d2t_psroipool_channels", _I, [_P, _I, _I, _P])
 _proto("d2t_corr_mask", _I, [_P, _I, _I, _I, _I, _P])
 SYMBOLS += ["d2t_psroipool_channels", "d2t_corr_mask"]
+# the lab build (csrc/Makefile `lab`) exports one more symbol; the product library does not
+IS_LAB_BUILD = hasattr(lib, "d2t_lab_build")
 
 
 def check(code: int, what: str) -> None:

@@ -11,7 +11,8 @@
  *                           (launcher pointwise_correlation_cuda.cu:178-210)
  *   d2t_corr_bwd_*       <- pointwise_correlation_backward  pointwise_correlation/pointwise_correlation.cpp:36-48
  *                           (launcher pointwise_correlation_cuda.cu:214-249)
- *                           (d2t_corr_bwd_workspace_bytes is non-zero OUTSIDE the tuned envelope and for f64: with that
+ *                           (d2t_corr_bwd_workspace_bytes is non-zero OUTSIDE the tuned envelope -- for the backward that includes
+ *                           maps lower than 17 rows -- and for f64: with that
  *                           scratch the tiled / blocked kernels run, without it the thread-per-element ones -- same values)
  *   d2t_roipool_fwd_*    <- roipool_forward                 roipool/roipool.cpp:22-32   (roipool_cuda.cu:130-157)
  *   d2t_roipool_bwd_*    <- roipool_backward                roipool/roipool.cpp:35-45   (roipool_cuda.cu:160-190)
@@ -28,7 +29,7 @@
  *     asynchronous, allocate nothing, synchronise nothing and are graph-capturable.
  *   - `ws` is caller-provided device scratch of at least the matching
  *     d2t_*_workspace_bytes(...) bytes (may be NULL when that returns 0), 16-byte aligned
- *     (D2T_EINVAL otherwise; every device allocation is).
+ *     (D2T_EINVAL otherwise; every device allocation is; not checked when ws_bytes is 0).
  *   - Return value: 0 on success; a negative D2T_E* code for argument errors; a
  *     positive value is a hipError_t from the launch.  The library keeps no pointers
  *     after return and is re-entrant (autograd calls backward from another thread).  Its only
@@ -69,9 +70,11 @@ int         d2t_version(void);
 const char* d2t_error_string(int code);
 
 /* The tuned envelope and what leaving it costs.  The gfx950-tuned kernels cover what the reference model uses
- * (cfg/default.yaml:48,50: D_MAX 8, K 7; correlation_tracker.py:26: stride 1): correlation d_max = 8, stride 1, W >= 20;
+ * (cfg/default.yaml:48,50: D_MAX 8, K 7; correlation_tracker.py:26: stride 1): correlation d_max = 8, stride 1, W >= 20 (backward: H >= 17 too);
  * pooling k = 7; float32.  Everything else -- and all of float64 -- runs type-generic kernels in the reference's order whose
- * results are bit-identical to the thread-per-element kernels D2T_IMPL_GENERIC selects (tested), in two tiers: the default
+ * results are bit-identical to the thread-per-element kernels D2T_IMPL_GENERIC selects (tested) -- with ONE exception: the float32
+ * ROIPool forward with k <= 16 and at least 32 RoIs stays on the summed-area kernel whatever k is (the contract of k = 7: within 1e-5 of
+ * the reference, NaN pattern exact; tests/test_roipool.py::test_forward_any_bin_count_summed_area_tables) -- in two tiers: the default
  * dispatch takes kernels that share the work the anchor repeats per thread (correlation f32, d_max <= 14: d2t_corr_fwd_mfma.hip /
  * d2t_corr_blocked.hip -- forward tiles with the FM1 window in LDS (d_max <= 8: on the f32 matrix pipe), backward four pixels x four
  * channels per thread from zero-padded row copies; pooling backward, k <= 32: d2t_pool_lists.hip -- per map row the lists of the bin rows / cells
@@ -90,25 +93,17 @@ const char* d2t_error_string(int code);
  *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)
  *   D2T_IMPL_MFMA    the tuned path, demanded: correlation returns D2T_EINVAL when its preconditions
  *                    (d_max = 8, stride 1, W >= 20) do not hold; the pooling ops fall back to generic */
-enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_MFMA_STRIP16 = 3, D2T_IMPL_BF16X3 = 4, D2T_IMPL_FAST = 5,
-       D2T_IMPL_MFMA_WIDE8 = 6, D2T_IMPL_MFMA_STRIP4 = 7 };
-/*   D2T_IMPL_MFMA_STRIP16  as D2T_IMPL_MFMA, but the correlation backward always takes the 16-wave strip kernel
- *                          (the default before the 8-wave one existed): same-process A/B measurements
- *   D2T_IMPL_BF16X3        as D2T_IMPL_MFMA, but the correlation backward (reference layout, map at least 17 rows high)
- *                          runs on the bf16 matrix pipe with every f32 operand split into three bf16 pieces (six piece
- *                          products per product): as accurate as the f32 chain (<= 1e-5 of sum|terms|, deterministic), not
- *                          the default -- an experiment kept selectable
- *   D2T_IMPL_FAST          as D2T_IMPL_AUTO, and the correlation FORWARD may re-associate its channel sum: small grids with
- *                          many channels (the model's B = 1 pairs with 1024 / 2048 channels) split the channels of a level
- *                          over several workgroups and add the partial sums in a fixed order -- deterministic, within 1e-5
- *                          of the reference's single ascending-channel chain, NOT bit-identical to it (needs the workspace
- *                          of d2t_corr_fwd*_workspace_bytes; without it the call runs as D2T_IMPL_AUTO).  Every other
- *                          selector keeps the forward bit-identical to the reference: exactness is the default, speed the
- *                          opt-in.  (B = 1, C = 2048, 38x75: 118 us exact, 63 us fast.)
- *   D2T_IMPL_MFMA_WIDE8 /  as D2T_IMPL_MFMA, but the correlation backward (reference layout, map at least 17 rows high) always
- *   D2T_IMPL_MFMA_STRIP4   takes the kernel on strips 8 pixels wide x 128 channels (csrc/d2t_corr_bwd8w.hip) / on strips 4 pixels
- *                          wide x up to 256 channels (csrc/d2t_corr_bwd8.hip): D2T_IMPL_AUTO picks between them by grid size;
- *                          these two exist for same-process A/B measurements and tests of either kernel */
+enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_FAST = 5 };
+/*   D2T_IMPL_FAST    as D2T_IMPL_AUTO, and the correlation FORWARD may re-associate its channel sum: small grids with
+ *                    many channels (the model's B = 1 pairs with 1024 / 2048 channels) split the channels of a level
+ *                    over several workgroups and add the partial sums in a fixed order -- deterministic, within 1e-5
+ *                    of the reference's single ascending-channel chain, NOT bit-identical to it (needs the workspace
+ *                    of d2t_corr_fwd*_workspace_bytes; without it the call runs as D2T_IMPL_AUTO).  Every other
+ *                    selector keeps the forward bit-identical to the reference: exactness is the default, speed the
+ *                    opt-in.
+ * Any other value is D2T_EINVAL.  (ABI 1.05 also enumerated 3, 4, 6, 7: one specific correlation-backward kernel each, for A/B
+ * measurements.  Those kernels lost their measurements and left the product library in 1.06; they build into the LAB library only --
+ * `make -C detect-to-track_amd/csrc lab`, selectors in csrc/lab/d2t_lab_selectors.h.) */
 
 /* ---------------- PointwiseCorrelation ---------------- */
 size_t d2t_corr_fwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size);
@@ -158,7 +153,7 @@ int d2t_corr_fwd_levels_f32(int n_levels, const float* const* fm0, const float* 
                             void* ws, size_t ws_bytes, int impl, d2t_stream_t stream);
 /* Scratch of the backward levels call for D2T_LAYOUT_CHANNEL_MAJOR: with it the gradient is first re-laid into the reference's
  * layout and the kernels of d2t_corr_bwd_f32 run on that copy (the tracker's three B = 1 levels: 205 us instead of 304 us with the
- * kernel that reads the channel-major layout in place -- which still runs when ws is NULL / too small; same 1e-5 contract).
+ * layout-aware thread-per-element kernels, which run when ws is NULL / too small -- D2T_EWS under D2T_IMPL_MFMA; same 1e-5 contract).
  * 0 for the reference layout and for shapes outside the tuned envelope. */
 size_t d2t_corr_bwd_levels_workspace_bytes(int n_levels, const int* C, int B, int H, int W, int d, int stride, int layout);
 

@@ -80,7 +80,8 @@ if __name__ == "__main__":
         made.append(CpuStub())
         return made[0]
 
-    argv = sys.argv[1:] + ["--no-cpu-baseline"]
+    import os
+    argv = sys.argv[1:] + ([] if os.environ.get("D2T_STUB_CPU_BASELINE") == "1" or "--no-cpu-baseline" in sys.argv[1:] else ["--no-cpu-baseline"])
     info = bench.main(argv, device_factory=factory, script=Path(__file__).resolve())
     a, stub = bench.parse_args(argv), made[0]
     settle = info["settle_steps"]                                # untimed clock-settling steps (bounded by wall time, in batches)
@@ -88,4 +89,7 @@ if __name__ == "__main__":
     n = stub.n_sets + a.warmup + settle + a.steps * (4 if a.graph else 2)   # + the timed steps and the event pass (+ 2 graph replays of them)
     assert stub.calls == {"fwd": n, "bwd": n}, stub.calls
     assert info["ranks_seen"] == a.gpus
-    print(f"stub rank {stub.rank} done", file=sys.stderr)
+    # rank -> device: what HipDevice would pick with one GPU per rank (RCCL) and when all ranks share one GPU (gloo rehearsal)
+    _, world, lr = bench.rank_env()
+    print(f"stub rank {stub.rank} done local_rank {lr} nccl_device {bench.device_index(lr, 'nccl', world)} "
+          f"shared_device {bench.device_index(lr, 'gloo', 1)}", file=sys.stderr)

@@ -111,7 +111,7 @@ def test_bench_rank_skeleton_under_torchrun():
     assert sum(k["us"] for k in d["kernels"]) <= d["event_pass"]["ms_per_step"] * 1e3 * 1.001
     assert d["event_pass"]["records_per_step"] == 2
     assert d["timing"]["value"].startswith("wall time of K eager steps") and d["graph_replay"]["ms_per_step"] >= 2 * (2 + 3) * 0.95
-    assert "cpu_baseline" not in d                          # rank 0 at N = 1 only
+    assert "cpu_baseline" not in d                          # the stub passes --no-cpu-baseline (see the N = 2 case below)
     # round-4 fields: the third roof per kernel (profiles/ta_roof.json), the op table (device layers without one: null), the backend
     for k in d["kernels"]:
         ta = k["roofline_ta"]
@@ -140,6 +140,51 @@ def test_bench_bare_form_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == K and d["config"]["global_batch"] == 16
     assert d["settle_steps"] >= 25 and d["settle_ms"] >= 30.0
     assert p.stderr.count("stub rank") == 2                 # both ranks ran to the end
+
+
+@pytest.mark.timeout(600)
+def test_bench_eight_ranks_one_line_and_device_map():
+    """World size 8 (BASELINE config 5's rank count) with the stub device over gloo, bare form: eight ranks take part
+    (ranks_seen), rank 0 prints the one JSON line, LOCAL_RANK r is device r under RCCL's one-GPU-per-rank rule and device 0
+    when eight ranks rehearse on one GPU; a rank without a GPU of its own is refused, not wrapped."""
+    K, W = 2, 1
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "tests" / "bench_stub_main.py"), "--gpus", "8", "--steps", str(K), "--warmup", str(W),
+           "--settle-ms", "10", "--graph", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "shard8"
+    assert d["scaling"] == "weak" and d["ms_per_step"] >= 8 * (2 + 3) * 0.95          # the slowest rank (rank 7: 8x sleeps) sets the time
+    done = [ln for ln in p.stderr.splitlines() if ln.startswith("stub rank")]
+    assert len(done) == 8
+    seen = sorted((int(w[2]), int(w[5]), int(w[7]), int(w[9])) for w in (ln.split() for ln in done))
+    assert seen == [(r, r, r, 0) for r in range(8)], seen                              # (rank, LOCAL_RANK, RCCL device, shared device)
+    sys.path.insert(0, str(ROOT))
+    import bench
+    with pytest.raises(SystemExit):
+        bench.device_index(1, "nccl", 1)                                               # two RCCL ranks on one GPU: refused
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_carry_a_cpu_baseline():
+    """N > 1: rank 0's line carries `cpu_baseline` too (north_star: the CPU figure beside the 2 / 4 / 8-GPU numbers) -- a shorter sample on
+    rank 0's share of the host threads, taken after everything timed."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", D2T_STUB_CPU_BASELINE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "tests" / "bench_stub_main.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--settle-ms", "10",
+           "--graph", "0", "--cpu-baseline-multi-s", "1.0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    cb = d["cpu_baseline"]
+    assert d["n_gpus"] == 2 and cb["kind"] == "port" and cb["unit"] == "Gvox/s" and cb["value"] > 0 and cb["cores"] >= 1
+    assert "rank 0 of 2" in cb["sample"] and cb["single_thread"]["cores"] == 1
 
 
 @pytest.mark.timeout(300)
