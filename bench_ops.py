@@ -29,6 +29,18 @@ HBM_GBS = 8000.0
 F32_TF = 157.3
 K = 7
 
+# rocprofv3-measured HBM bytes per call of every (op, shape, direction) below: profiles/traffic.json "ops", written by tools/ops_pmc.sh
+# (separate --pmc FETCH_SIZE / WRITE_SIZE passes of THIS script; bytes = (2 FETCH_SIZE + WRITE_SIZE) KB, FETCH doubled per the MI355X guide)
+try:
+    TRAFFIC = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("ops", {})
+except Exception:
+    TRAFFIC = {}
+MARKER = None          # tools/ops_pmc.sh: called with (label, calls) in front of every timed series
+
+
+def label_of(op, shape, direction):
+    return f"{op}/{shape}/{direction}"
+
 
 def _ws(nbytes, dev):
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
@@ -44,7 +56,9 @@ def random_rois(R, seed):
     return np.concatenate([rng.uniform(0.15, 0.85, (R, 2)), rng.uniform(0.05, 0.6, (R, 2))], 1).astype(np.float32)
 
 
-def timed(fn, iters, nsets):
+def timed(fn, iters, nsets, label=None):
+    if MARKER is not None:
+        MARKER(label, iters + 3)
     for i in range(3):
         fn(i % nsets)
     torch.cuda.synchronize()
@@ -69,6 +83,11 @@ def _entry(op, shape, direction, us, nbytes, flops, impl, note=None):
         e.update(roof="hbm", frac=round(nbytes / us / 1e3 / HBM_GBS, 4))
     if note:
         e["note"] = note
+    t = TRAFFIC.get(label_of(op, shape, direction))
+    if t:                                            # rocprof-reported HBM bytes of the same call (north_star: achieved HBM GB/s)
+        e["traffic"] = int(t["hbm_bytes"])
+        e["traffic_over_algorithmic"] = round(t["hbm_bytes"] / nbytes, 3)
+        e["hbm_GBps_measured"] = round(t["hbm_bytes"] / us / 1e3, 1)
     return e
 
 
@@ -92,9 +111,9 @@ def measure_roipool(dev, R, C, H, W, impl, iters, st):
     nb = R * C * K * K * 4 + C * H * W * 4 + R * 16
     shape = f"R{R}_C{C}_{H}x{W}_k{K}"
     tf = timed(lambda i: _check(L.d2t_roipool_fwd_f32(fm[i].data_ptr(), rois.data_ptr(), out[i].data_ptr(), R, C, H, W, K,
-                                                      wf.data_ptr(), nf, impl, st)), iters, nsets)
+                                                      wf.data_ptr(), nf, impl, st)), iters, nsets, label_of("roipool", shape, "fwd"))
     tb = timed(lambda i: _check(L.d2t_roipool_bwd_f32(go[i].data_ptr(), rois.data_ptr(), gin[i].data_ptr(), R, C, H, W, K,
-                                                      wb.data_ptr(), nbw, impl, st)), iters, nsets)
+                                                      wb.data_ptr(), nbw, impl, st)), iters, nsets, label_of("roipool", shape, "bwd"))
     return [_entry("roipool", shape, "fwd", tf, nb, 0, impl), _entry("roipool", shape, "bwd", tb, nb, 0, impl)]
 
 
@@ -112,9 +131,9 @@ def measure_psroipool(dev, R, nT, H, W, impl, iters, st):
     nb = R * nT * K * K * 4 + C * H * W * 4 + R * 16
     shape = f"R{R}_nT{nT}_{H}x{W}_k{K}"
     tf = timed(lambda i: _check(L.d2t_psroipool_fwd_f32(fm[i].data_ptr(), rois.data_ptr(), out[i].data_ptr(), R, nT, H, W, K,
-                                                        wf.data_ptr(), nfw, impl, st)), iters, nsets)
+                                                        wf.data_ptr(), nfw, impl, st)), iters, nsets, label_of("psroipool", shape, "fwd"))
     tb = timed(lambda i: _check(L.d2t_psroipool_bwd_f32(go[i].data_ptr(), rois.data_ptr(), gin[i].data_ptr(), R, nT, H, W, K,
-                                                        wb.data_ptr(), nbw, impl, st)), iters, nsets)
+                                                        wb.data_ptr(), nbw, impl, st)), iters, nsets, label_of("psroipool", shape, "bwd"))
     note = "launch/latency-bound: a few MB per call (SURVEY 8d)"
     return [_entry("psroipool", shape, "fwd", tf, nb, 0, impl, note), _entry("psroipool", shape, "bwd", tb, nb, 0, impl, note)]
 
@@ -135,10 +154,10 @@ def measure_corr(dev, B, C, H, W, impl, iters, st):
     shape = f"B{B}_C{C}_{H}x{W}_d8"
     vox = B * H * W * 289
     tf = timed(lambda i: _check(L.d2t_corr_fwd_f32(f0[i].data_ptr(), f1[i].data_ptr(), out[i].data_ptr(),
-                                                    B, C, H, W, d, 1, wsf.data_ptr() if nws else 0, nws, impl, st)), iters, nsets)
+                                                    B, C, H, W, d, 1, wsf.data_ptr() if nws else 0, nws, impl, st)), iters, nsets, label_of("corr", shape, "fwd"))
     tb = timed(lambda i: _check(L.d2t_corr_bwd_f32(go[i].data_ptr(), f0[i].data_ptr(), f1[i].data_ptr(),
                                                     g0[i].data_ptr(), g1[i].data_ptr(),
-                                                    B, C, H, W, d, 1, 0, 0, impl, st)), iters, nsets)
+                                                    B, C, H, W, d, 1, 0, 0, impl, st)), iters, nsets, label_of("corr", shape, "bwd"))
     ef = _entry("corr", shape, "fwd", tf, 2 * inb + outb, fl, impl)
     eb = _entry("corr", shape, "bwd", tb, outb + 4 * inb, 2 * fl, impl)
     ef["gvox_s"], eb["gvox_s"] = round(vox / tf / 1e3, 2), round(vox / tb / 1e3, 2)
@@ -146,7 +165,8 @@ def measure_corr(dev, B, C, H, W, impl, iters, st):
     if nws and impl == _native.IMPL_AUTO:
         # the opt-in forward (D2T_IMPL_FAST): channels of a small grid split over workgroups, within 1e-5, not bit-identical
         tq = timed(lambda i: _check(L.d2t_corr_fwd_f32(f0[i].data_ptr(), f1[i].data_ptr(), out[i].data_ptr(),
-                                                        B, C, H, W, d, 1, wsf.data_ptr(), nws, _native.IMPL_FAST, st)), iters, nsets)
+                                                        B, C, H, W, d, 1, wsf.data_ptr(), nws, _native.IMPL_FAST, st)), iters, nsets,
+                   label_of("corr", shape, "fwd_fast"))
         eq = _entry("corr", shape, "fwd_fast", tq, 2 * inb + outb, fl, _native.IMPL_FAST,
                     "opt-in D2T_IMPL_FAST: channel split, deterministic, within 1e-5 of the reference")
         eq["gvox_s"] = round(vox / tq / 1e3, 2)
@@ -184,9 +204,10 @@ def measure_tracker(dev, impl, iters):
     nb = sum(2 * C * H * W * 4 for C in Cs) + 3 * 289 * H * W * 4
     fl = sum(corr_flops(1, C, H, W) for C in Cs)
     shape = "3corr+cat+roipool_R8_38x75"
-    return [_entry("tracker_fwd", shape, "unfused", timed(unfused, iters, 1), nb, fl, impl),
-            _entry("tracker_fwd", shape, "fused", timed(fused, iters, 1), nb, fl, impl),
-            _entry("tracker_fwd", shape, "fused_fast", timed(lambda i: fused(i, _native.IMPL_FAST), iters, 1), nb, fl, _native.IMPL_FAST)]
+    return [_entry("tracker_fwd", shape, "unfused", timed(unfused, iters, 1, label_of("tracker_fwd", shape, "unfused")), nb, fl, impl),
+            _entry("tracker_fwd", shape, "fused", timed(fused, iters, 1, label_of("tracker_fwd", shape, "fused")), nb, fl, impl),
+            _entry("tracker_fwd", shape, "fused_fast", timed(lambda i: fused(i, _native.IMPL_FAST), iters, 1, label_of("tracker_fwd", shape, "fused_fast")),
+                   nb, fl, _native.IMPL_FAST)]
 
 
 def measure(dev="cuda:0", impl=0, iters=20, full=False):
@@ -214,7 +235,18 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--full", type=int, default=1, help="1: also the metric shape, the small PSROIPool shapes and the tracker glue")
+    ap.add_argument("--pmc-markers", default=None, help="tools/ops_pmc.sh: write (label, calls) of every timed series to this JSON-lines file and "
+                    "launch a marker kernel (k_corr_mask) in front of each, so that a rocprofv3 --pmc pass can be cut into the series")
     args = ap.parse_args()
+    if args.pmc_markers:
+        global MARKER
+        mk = torch.empty(64, dtype=torch.uint8, device="cuda:0")
+        fh = open(args.pmc_markers, "w")
+
+        def MARKER(label, calls):
+            fh.write(json.dumps({"label": label, "calls": calls}) + "\n")
+            fh.flush()
+            _check(L.d2t_corr_mask(mk.data_ptr(), 1, 1, 0, 1, torch.cuda.current_stream().cuda_stream))
     for e in measure("cuda:0", args.impl, args.iters, bool(args.full)):
         print(json.dumps(e), flush=True)
 

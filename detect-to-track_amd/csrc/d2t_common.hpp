@@ -120,6 +120,30 @@ inline int lab_env_int(const char*, int dflt) { return dflt; }
 inline const char* lab_env_str(const char*) { return nullptr; }
 #endif
 
+// In-kernel clock reads of knob builds (-DD2T_ENV_KNOBS; tools/kstamps.py): [workgroup][16] s_memtime values of thread 0.  A translation
+// unit that stamps says D2T_KSTAMP_DEFINE(setter) once (the library is built without relocatable device code: the pointer is per unit) and
+// D2T_KSTAMP(i) where it wants a clock read.  The product library is built without D2T_ENV_KNOBS: no stamp executes there.
+#ifdef D2T_ENV_KNOBS
+#define D2T_KSTAMP_DEFINE(setter)                                                                     \
+    static __device__ unsigned long long* kstamps_;                                                   \
+    extern "C" int setter(void* p)                                                                    \
+    {                                                                                                 \
+        unsigned long long* q = static_cast<unsigned long long*>(p);                                  \
+        return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(kstamps_), &q, sizeof(q)));              \
+    }
+#define D2T_KSTAMP(i)                                                                                 \
+    do {                                                                                              \
+        if (kstamps_ && threadIdx.x == 0) {                                                           \
+            unsigned long long t_;                                                                    \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            kstamps_[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_;                  \
+        }                                                                                             \
+    } while (0)
+#else
+#define D2T_KSTAMP_DEFINE(setter)
+#define D2T_KSTAMP(i)
+#endif
+
 inline bool fits_i32(long long v) { return v >= 0 && v <= 2147483647LL; }
 
 inline int grid_for(long long work_items, int block, int cap = 256 * 16) {

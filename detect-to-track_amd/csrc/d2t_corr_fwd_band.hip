@@ -23,17 +23,48 @@
 
 namespace d2t { namespace tuned {
 
+#ifdef D2T_ENV_KNOBS
+// in-kernel stamps of the scan build (tools/band_scan.py --stamps): [workgroup][16] clock reads of compute wave 0 (0-4) and of the first
+// loader wave (8-13), s_memrealtime at entry / exit (14, 15).  The product library is built without D2T_ENV_KNOBS: no stamp executes there.
+__device__ unsigned long long* band_stamps;
+#define BAND_STAMP(cond, i)                                                                           \
+    do {                                                                                              \
+        if (band_stamps && (cond) && (threadIdx.x & 63) == 0) {                                       \
+            unsigned long long t_;                                                                    \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            band_stamps[(size_t)blockIdx.x * 16 + (i)] = t_;                                          \
+        }                                                                                             \
+    } while (0)
+#define BAND_STAMP_RT(cond, i)                                                                        \
+    do {                                                                                              \
+        if (band_stamps && (cond) && (threadIdx.x & 63) == 0) {                                       \
+            unsigned long long t_;                                                                    \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            band_stamps[(size_t)blockIdx.x * 16 + (i)] = t_;                                          \
+        }                                                                                             \
+    } while (0)
+#define BAND_CLK(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define BAND_STAMP(cond, i)
+#define BAND_STAMP_RT(cond, i)
+#define BAND_CLK(var)
+#endif
+
 namespace {
 
 constexpr int imin(int a, int b) { return a < b ? a : b; }
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 constexpr int MAXG = WR * NCG;                                       // 95 slot groups of an unclipped tile window
+constexpr int PATCH = 4 * CW + 1;                                    // floats per pixel in a task's output patch: its 16 groups span <= 4 window rows x 17 cells
 
-template <int TW, int NB, int KC, int RING, int WL>
+// TW tiles side by side, NB tile-groups per workgroup, HT waves per (tile, tile-group) task (2: each wave multiplies two of the
+// task's four N-tiles), KC channels per staged chunk, RING chunk images, WL loader waves.
+template <int TW, int NB, int HT, int KC, int RING, int WL>
 struct Band {
     static constexpr int NG = TW + 4;                                // 16-byte column groups of the block's window
-    static constexpr int WC = TW * NB;                               // compute waves: one (tile, tile-group) task each
+    static constexpr int WC = TW * NB * HT;                          // compute waves
     static constexpr int WAVES = WC + WL, THREADS = 64 * WAVES;      // + WL loader waves: they issue every LDS-DMA instruction
+    static constexpr int NS = 4 / HT;                                // N-tiles (accumulators) per compute wave
     static constexpr int NQ = (6 + NB - 1) / NB;                     // band-sets per tile row and block
     static constexpr int rows_of(int q) { return (imin(16 * (q + 1) * NB, MAXG) - 1) / NCG - (16 * q * NB) / NCG + 1; }
     static constexpr int max_rows() { int m = 0; for (int q = 0; q < NQ; ++q) m = imax(m, rows_of(q)); return m; }
@@ -41,27 +72,30 @@ struct Band {
     static constexpr int P = (NROWS * NG + 15) / 16 * 16;            // slots per channel plane: plane stride = 0 mod 64 dwords
     static constexpr int BPL = 4 * P, APL = 16 * TW;                 // floats per channel: FM1 window part / FM0 pixels
     static constexpr int BUF = KC * (BPL + APL);                     // floats per staged chunk
-    static constexpr int BI = KC * P / 64, AI = KC * 4 * TW / 64;    // DMA wave-instructions per chunk: FM1 / FM0
+    static constexpr int BI = KC * P / 64, AI = (KC * 4 * TW + 63) / 64;   // DMA wave-instructions (64 pieces of 16 bytes) per chunk: FM1 / FM0
     static constexpr int NDMA = (BI + AI + WL - 1) / WL;             // per loader wave and chunk (surplus ones are parked)
     static constexpr int DUMMY = 256;                                // floats: where parked DMA instructions land
-    static constexpr int LDS = RING * BUF + DUMMY;
+    static constexpr int RINGF = RING * BUF + DUMMY;
+    static constexpr int EPI = WC * 16 * PATCH;                      // epilogue: a patch of 16 pixels per compute wave (aliases the ring)
+    static constexpr int LDS = RINGF > EPI ? RINGF : EPI;
     static constexpr int INFLIGHT = (RING - 2) * NDMA;               // a loader's DMA instructions that may be outstanding at a barrier
-    static_assert(WAVES <= 16 && KC % 8 == 0 && (KC * 4 * TW) % 64 == 0 && (KC * P) % 64 == 0 && RING >= 3, "shape");
+    static_assert(WAVES <= 16 && KC % 8 == 0 && (KC * P) % 64 == 0 && RING >= 3 && (HT == 1 || HT == 2), "shape");
     static_assert(INFLIGHT <= 63, "vmcnt is a 6-bit counter");
     static_assert(LDS * 4 <= 160 * 1024, "LDS budget");
 };
 
 // One workgroup: batch item b, tile row u, tile columns [TW vb, TW vb + TW), tile-groups [NB q, NB q + NB).
-template <int TW, int NB, int KC, int RING, int WL>
-__global__ void __launch_bounds__((TW * NB + WL) * 64)
+template <int TW, int NB, int HT, int KC, int RING, int WL>
+__global__ void __launch_bounds__((TW * NB * HT + WL) * 64)
 k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
                 int C, int H, int W, int tiles_i, int tiles_j, int blocks_j, CellLayout lay)
 {
-    using S = Band<TW, NB, KC, RING, WL>;
+    using S = Band<TW, NB, HT, KC, RING, WL>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    BAND_STAMP(wave == 0, 0); BAND_STAMP_RT(wave == 0, 14); BAND_STAMP(wave == S::WC, 8);
     // logical id (band-set innermost: the band-sets of a block share its FM0 pixels and overlap in window rows; give every
     // XCD a contiguous run of the logical order)
     int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -86,31 +120,33 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     float* outb = out + (size_t)b * lay.bs;
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outb, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
 
-    // ---- this wave's role.  Waves [0, WC) compute: tile v of the block, tile-group T.  Waves [WC, WC + WL) are LOADERS: they issue
-    // every LDS-DMA instruction of the workgroup.  (With the DMA instructions dealt to the computing waves -- the first version --
-    // every wave issued its share right behind the chunk's barrier, all of them queued at the CU's address unit together and no
-    // MFMA was issued meanwhile: 0.61 us per chunk where the matrix work is 0.43 us; a wave's instruction stream is in order.)
+    // ---- this wave's role.  Waves [0, WC) compute: task = (tile v of the block, tile-group T), HT waves per task (wave half hs takes
+    // N-tiles [NS hs, NS hs + NS)).  Waves [WC, WC + WL) are LOADERS: they issue every LDS-DMA instruction of the workgroup.  (With
+    // the DMA instructions dealt to the computing waves -- the first version -- every wave issued its share right behind the chunk's
+    // barrier, all of them queued at the CU's address unit together and no MFMA was issued meanwhile; a wave's stream is in order.)
     const bool loader = wave >= S::WC;                               // wave-uniform
-    const int v = wave % TW, T = NB * q + (wave / TW) % NB;
+    const int task = wave / HT, hs = wave - task * HT;
+    const int v = task % TW, T = NB * q + (task / TW) % NB;
     const bool t_on = !loader && 16 * T < ng && v0 + v < tiles_j;    // wave-uniform
     int gi = 16 * T + n;
     const bool lane_on = t_on && gi < ng;
     gi = gi < ng ? gi : ng - 1;
     gi = gi < g_lo ? g_lo : gi;                                      // (a dead wave still reads a staged slot)
     const int rho = wa + gi / NCG, cg = gi - (gi / NCG) * NCG;       // displaced row, column group inside the tile's window
-    const int l_off = ((rho - R0) * S::NG + v + cg) * 4 + g * S::BPL;
+    const int l_off = ((rho - R0) * S::NG + v + cg) * 4 + S::NS * hs + g * S::BPL;
     const int a_off = KC * S::BPL + g * S::APL + (n >> 2) * (4 * TW) + 4 * v + (n & 3);
 
-    f32x4 acc[4];
+    typedef float frag_t __attribute__((ext_vector_type(S::NS)));
+    f32x4 acc[S::NS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S::NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nchunks = (C + KC - 1) / KC;
 
     // Ring protocol (both roles meet at ONE barrier per chunk).  Barrier #k publishes chunk k: every loader has waited until at
     // most INFLIGHT = (RING - 2) NDMA of its DMA instructions are outstanding (LDS-DMA retires in order: chunks k+1 .. k+RING-2
     // may be in flight), every computing wave has its fragments of chunk k-1 in registers (lgkmcnt(0)), so behind the barrier
     // the loaders overwrite the slot of chunk k-1 with chunk k+RING-1.  The barrier sits in the MIDDLE of a chunk's MFMAs: the
-    // fragments of chunk k+1 are fetched under the second half of chunk k's.
+    // fragments of chunk k+1 are fetched under the second half of chunk k's.  Chunk 0 alone is staged in front of barrier #0.
     if (loader) {
         // DMA plan: position k of a loader's sequence is instruction x = (wave - WC) + WL k of the chunk -- x < BI: 64 pieces of the FM1
         // image [channel][row][column group] (plane pitch P slots), BI <= x < BI + AI: 64 pieces (channel, pixel row, tile) of the
@@ -128,43 +164,61 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
                 const int row = rem / S::NG, cgb = rem - row * S::NG;   // pad slots: row >= NROWS >= nrows
                 dv[k] = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cgb) * 4 : OOR;
             } else {
-                const int xa = x - S::BI;
-                const int e = xa * 64 + lane;
+                const int e = (x - S::BI) * 64 + lane;
                 const int ch = e / (4 * TW), rem = e - ch * (4 * TW);
                 const int prow = rem / TW, pv = rem - prow * TW;
                 const int pi = 4 * u + prow;
-                dv[k] = xa < S::AI && pi < H && v0 + pv < tiles_j ? (ch * HW + pi * W + j0 + 4 * pv) * 4 : OOR;
+                dv[k] = x < S::BI + S::AI && ch < KC && pi < H && v0 + pv < tiles_j ? (ch * HW + pi * W + j0 + 4 * pv) * 4 : OOR;
             }
         }
         const int chunk_bytes = KC * HW * 4;
         auto stage = [&](int slot, int chunk) {                      // chunks past the end of C arrive as zeros
             const int cb = chunk * chunk_bytes;
-            float* buf = smem + slot * S::BUF;
+            // chunks nobody multiplies (behind chunk nchunks, which is fetched but unused) are parked whole: the ring is quiet when the
+            // last barrier has been passed, and the epilogue may use its memory
+            float* buf = chunk <= nchunks ? smem + slot * S::BUF : nullptr;
+            float* dummy = smem + RING * S::BUF;
 #pragma unroll
             for (int k = 0; k < S::NDMA; ++k) {
                 const int x = lw + WL * k;                           // wave-uniform
-                const int vo = dv[k] == OOR ? OOR : dv[k] + cb;
-                if (x < S::BI) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(buf + x * 256), 16, vo, 0, 0, 0);
-                else if (x < S::BI + S::AI) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)(buf + KC * S::BPL + (x - S::BI) * 256), 16, vo, 0, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)(smem + RING * S::BUF), 16, vo, 0, 0, 0);   // parked (vo = OOR): keeps the count equal
+                const int vo = dv[k] == OOR || !buf ? OOR : dv[k] + cb;
+                float* dst = x < S::BI ? (buf ? buf + x * 256 : dummy)
+                           : x < S::BI + S::AI ? (buf ? buf + KC * S::BPL + (x - S::BI) * 256 : dummy) : dummy;   // else parked (vo = OOR): keeps the count equal
+                if (x < S::BI) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, vo, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)dst, 16, vo, 0, 0, 0);
             }
         };
+        stage(0, 0);
+        BAND_STAMP(lw == 0, 9);
+        dma_wait_barrier<0>();                                       // barrier #0: chunk 0 has landed
+        BAND_STAMP(lw == 0, 10);
 #pragma unroll
-        for (int p = 0; p < RING - 1; ++p) stage(p, p);
-        dma_wait_barrier<S::INFLIGHT>();                             // barrier #0: chunk 0 has landed
+        for (int p = 1; p < RING - 1; ++p) stage(p, p);              // chunks 1 .. RING-2 go out under the first MFMAs
         int slot = RING - 1;                                         // where chunk ch + RING - 1 goes
+#ifdef D2T_ENV_KNOBS
+        unsigned long long t_issue = 0, t_wait = 0, ta_, tb_, tc_;
+#endif
         for (int ch = 0; ch < nchunks; ++ch) {
+            BAND_CLK(ta_);
             stage(slot, ch + RING - 1);
+            BAND_CLK(tb_);
             slot = slot + 1 == RING ? 0 : slot + 1;
             dma_wait_barrier<S::INFLIGHT>();                         // barrier #(ch+1): chunk ch+1 has landed
+#ifdef D2T_ENV_KNOBS
+            BAND_CLK(tc_); t_issue += tb_ - ta_; t_wait += tc_ - tb_;
+#endif
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the zero chunks staged past the end
+        BAND_STAMP(lw == 0, 11);
+#ifdef D2T_ENV_KNOBS
+        if (band_stamps && lw == 0 && lane == 0) { band_stamps[(size_t)blockIdx.x * 16 + 12] = t_issue; band_stamps[(size_t)blockIdx.x * 16 + 13] = t_wait; }
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the parked instructions staged past the end
     } else {
-        struct Frag { f32x4 q[KC / 4]; float a[KC / 4]; };
+        struct Frag { frag_t q[KC / 4]; float a[KC / 4]; };
         auto fetch = [&](Frag& f, const float* cur) {
 #pragma unroll
             for (int ks = 0; ks < KC / 4; ++ks) {
-                f.q[ks] = *reinterpret_cast<const f32x4*>(cur + l_off + ks * 4 * S::BPL);
+                f.q[ks] = *reinterpret_cast<const frag_t*>(cur + l_off + ks * 4 * S::BPL);
                 f.a[ks] = cur[a_off + ks * 4 * S::APL];
             }
         };
@@ -173,10 +227,11 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
 #pragma unroll
             for (int ks = ks_lo; ks < ks_hi; ++ks)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc[s] = D2T_MFMA(f.a[ks], f.q[ks][s], acc[s]);
+                for (int s = 0; s < S::NS; ++s) acc[s] = D2T_MFMA(f.a[ks], f.q[ks][s], acc[s]);
         };
         Frag cur_f, nxt_f;
         lds_barrier();                                               // barrier #0
+        BAND_STAMP(wave == 0, 1);
         fetch(cur_f, smem);
         int slot = 0;                                                // ring slot of chunk ch
         for (int ch = 0; ch < nchunks; ++ch) {
@@ -189,55 +244,86 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
             cur_f = nxt_f;
             slot = next_slot;
         }
+        BAND_STAMP(wave == 0, 2);
     }
 
-    // ---- epilogue: straight from the accumulators.  acc[s][r] belongs to pixel (row g, column r) of the tile and window
-    // slot (rho, column 4 cg + s): cell ci = rho - i + d, cj = 4 cg + s - r of that pixel.
-    const int i = 4 * u + g, ci = rho - i + DT;
-    if (lane_on && i < H && ci >= 0 && ci <= 2 * DT) {
-        const int jt = j0 + 4 * v;
+    // ---- epilogue.  acc[s][r] belongs to pixel (row g, column r) of the tile and window slot (rho, column 4 cg + NS hs + s): cell
+    // ci = rho - i + d, cj = 4 cg + NS hs + s - r of that pixel.  A task's cells of a pixel are ONE contiguous run of its 17 x 17 block
+    // (the task's groups in row-major order), so a wave scatters its accumulators into a private LDS patch [16 pixels][PATCH] -- structural
+    // zeros (cj = 16, ci = 16, displaced columns outside the map) included -- and the task's waves store the runs with consecutive
+    // lanes on consecutive cells.  (Straight from the registers, as at first: 12-16 exec-masked store instructions per wave, each
+    // touching a dozen lines -- and 4 KB of straight-line code that every wave of the chip fetched cold at the same moment.)
+    __syncthreads();                                                 // every wave is past its last read of the ring; the ring is quiet
+    BAND_STAMP(wave == 0, 5);
+    const int gf = 16 * T, gl = (gf + 15 < ng ? gf + 15 : ng - 1);   // the task's first / last group (wave-uniform)
+    const int rho_f = wa + gf / NCG, cg_f = gf - (gf / NCG) * NCG, rho_l = wa + gl / NCG, cg_l = gl - (gl / NCG) * NCG;
+    float* patch = smem + task * 16 * PATCH;
+    if (lane_on) {
+        const int i = 4 * u + g, ci = rho - i + DT;
+        const int krow = (rho - rho_f) * CW;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int j = jt + r;
-            if (j < W) {
-                const int pix_off = (i * W + j) * lay.ps + ci * CW * lay.cs;
+            const int j = j0 + 4 * v + r;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int cj = 4 * cg + s - r, dj = j + cj - DT;
-                    if (cj >= 0 && cj <= 2 * DT) {
-                        const float val = ci < 2 * DT && cj < 2 * DT && dj >= 0 && dj < W ? acc[s][r] : 0.f;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, (pix_off + cj * lay.cs) * 4, 0, 0);
-                    }
-                }
+            for (int s = 0; s < S::NS; ++s) {
+                const int cj = 4 * cg + S::NS * hs + s - r, dj = j + cj - DT;
+                if (cj >= 0 && cj <= 2 * DT)
+                    patch[(4 * g + r) * PATCH + krow + cj] = ci < 2 * DT && cj < 2 * DT && dj >= 0 && dj < W ? acc[s][r] : 0.f;
             }
         }
     }
-    // orphan rows: cells whose displaced row lies outside the tile row's window -- above the map (first band-set), below
-    // it or ci = 16 of the tile's last pixel row (last band-set): structural zeros nobody computes
+    if (HT > 1) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // HT = 1: the patch is the wave's own
+    if (t_on) {
+        // pixel p = (row pg, column pr) of the tile: its run is patch[p][kA .. kB]; cell index in the pixel's block = fb + k
+        for (int e = hs * 64 + lane; e < 16 * PATCH; e += 64 * HT) {
+            const int p = e / PATCH, k = e - p * PATCH;
+            const int pg = p >> 2, pr = p & 3;
+            const int i = 4 * u + pg, j = j0 + 4 * v + pr;
+            const int rlo = rho_f > i - DT ? rho_f : i - DT, rhi = rho_l < i + DT ? rho_l : i + DT;
+            int cjA = 4 * cg_f - pr; cjA = rlo == rho_f && cjA > 0 ? cjA : 0;
+            int cjB = 4 * cg_l + 3 - pr; cjB = rhi == rho_l && cjB < 2 * DT ? cjB : 2 * DT;
+            const int kA = (rlo - rho_f) * CW + cjA, kB = (rhi - rho_f) * CW + cjB;
+            if (i < H && j < W && rlo <= rhi && k >= kA && k <= kB) {
+                const int cell = (rho_f - i + DT) * CW + k;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, patch[e]), ro, ((i * W + j) * lay.ps + cell * lay.cs) * 4, 0, 0);
+            }
+        }
+    }
+    BAND_STAMP(wave == 0, 3);
+    // orphan rows: cells whose displaced row lies outside the tile row's window -- above the map (first band-set: ci < d - i), below
+    // it or ci = 16 of the tile's last pixel row (last band-set: ci >= wb - i + d): structural zeros nobody computes.  Per pixel they
+    // are one or two contiguous runs of whole 17-cell rows; consecutive threads take consecutive cells.
     if (q == 0 || q == q_last) {
-        for (int e = tid; e < 16 * TW * CW; e += S::THREADS) {
-            const int p = e / CW, oci = e - p * CW;
-            const int ov = p >> 4, prow = (p >> 2) & 3, r = p & 3;
-            const int oi = 4 * u + prow, oj = j0 + 4 * ov + r;
-            const int orho = oi + oci - DT;
-            const bool mine = (orho < wa && q == 0) || (orho >= wb && q == q_last);
-            if (mine && oi < H && oj < W) {
-                const int off = (oi * W + oj) * lay.ps + oci * CW * lay.cs;
-#pragma unroll
-                for (int cj = 0; cj < CW; ++cj) __builtin_amdgcn_raw_buffer_store_b32(0u, ro, (off + cj * lay.cs) * 4, 0, 0);
+        for (int og = 0; og < 4; ++og) {
+            const int oi = 4 * u + og;
+            if (oi >= H) break;
+            int n_top = q == 0 ? DT - oi : 0;
+            n_top = n_top < 0 ? 0 : n_top;                           // (<= 8)
+            int b_lo = q == q_last ? wb - oi + DT : CW;
+            b_lo = b_lo > CW ? CW : b_lo;                            // (>= 9: wb > oi)
+            const int L = (n_top + CW - b_lo) * CW;                  // orphan cells per pixel of this pixel row
+            for (int e = tid; e < 4 * TW * L; e += S::THREADS) {
+                const int pj = e / L, k = e - pj * L;
+                const int cell = k < n_top * CW ? k : b_lo * CW + (k - n_top * CW);
+                const int oj = j0 + pj;
+                if (oj < W) __builtin_amdgcn_raw_buffer_store_b32(0u, ro, ((oi * W + oj) * lay.ps + cell * lay.cs) * 4, 0, 0);
             }
         }
     }
+#ifdef D2T_ENV_KNOBS
+    if (band_stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been acknowledged
+    BAND_STAMP(wave == 0, 4); BAND_STAMP_RT(wave == 0, 15);
+#endif
 }
 
-template <int TW, int NB, int KC, int RING, int WL>
+template <int TW, int NB, int HT, int KC, int RING, int WL>
 int launch_band(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, CellLayout lay, hipStream_t st)
 {
-    using S = Band<TW, NB, KC, RING, WL>;
+    using S = Band<TW, NB, HT, KC, RING, WL>;
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP, blocks_j = (tiles_j + TW - 1) / TW;
     const long long nwg = 1LL * B * tiles_i * blocks_j * S::NQ;
     if (nwg > 0x7fffffffLL) return D2T_ETOOBIG;
-    auto kfn = k_corr_fwd_band<TW, NB, KC, RING, WL>;
+    auto kfn = k_corr_fwd_band<TW, NB, HT, KC, RING, WL>;
     D2T_ENSURE_DYNAMIC_LDS(kfn, S::LDS * 4);
     hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(S::THREADS), S::LDS * 4, st, fm0, fm1, out, C, H, W, tiles_i, tiles_j, blocks_j, lay);
     return launch_status();
@@ -245,9 +331,7 @@ int launch_band(const float* fm0, const float* fm1, float* out, int B, int C, in
 
 }  // namespace
 
-// Which shape of workgroup for a grid of B items of H x W (0 = the band kernels do not take it).  Cost model per 16-channel
-// chunk on the busiest CU, in cycles: matrix pipe 512 per task on its busiest SIMD, L1-miss path 2.7 per 128-byte line
-// (ta_roof.json) -- see the table in the file header; workgroups are dealt evenly over the 256 CUs.
+// Which shape of workgroup for a grid of B items of H x W (0 = the band kernels do not take it).  id = 100 HT + 10 TW + NB.
 int corr_fwd_band_config(int B, int H, int W)
 {
     const int forced = lab_env_int("D2T_BAND_CFG", -1);
@@ -255,46 +339,41 @@ int corr_fwd_band_config(int B, int H, int W)
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     const long long tasks = 6LL * B * tiles_i * tiles_j;
     if (tasks > 2600) return 0;                                      // larger grids: the segment kernels of d2t_corr_tuned.hip
-    struct Cand { int id, tw, nb; double lines; };
-    static const Cand cands[] = {{41, 4, 1, 14.0}, {42, 4, 2, 20.0}, {43, 4, 3, 26.0}, {23, 2, 3, 22.5}};
-    int best = 0; double best_t = 1e30;
-    for (const Cand& c : cands) {
-        const long long nwg = 1LL * B * tiles_i * ((tiles_j + c.tw - 1) / c.tw) * ((6 + c.nb - 1) / c.nb);
-        const double per_cu = (double)((nwg + 255) / 256);
-        const double mfma = per_cu * 512.0 * ((c.tw * c.nb + 3) / 4);
-        const double ta = per_cu * c.lines * 16 * 2.7;
-        const double t = (mfma > ta ? mfma : ta) + 120.0;           // + barrier / fetch per chunk
-        if (t < best_t) { best_t = t; best = c.id; }
-    }
-    return best;
+    return 141;
 }
 
 int corr_fwd_band_f32(int cfg, const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, CellLayout lay, hipStream_t st)
 {
     switch (cfg) {
-#define D2T_BAND_CASE(id, TW, NB, KC, RING, WL) case id: return launch_band<TW, NB, KC, RING, WL>(fm0, fm1, out, B, C, H, W, lay, st);
-        D2T_BAND_CASE(41, 4, 1, 16, 4, 2)
-        D2T_BAND_CASE(42, 4, 2, 16, 4, 2)
-        D2T_BAND_CASE(43, 4, 3, 16, 4, 2)
-        D2T_BAND_CASE(23, 2, 3, 16, 4, 2)
-        D2T_BAND_CASE(22, 2, 2, 16, 4, 2)
+#define D2T_BAND_CASE(id, TW, NB, HT, KC, RING, WL) case id: return launch_band<TW, NB, HT, KC, RING, WL>(fm0, fm1, out, B, C, H, W, lay, st);
+        D2T_BAND_CASE(141, 4, 1, 1, 16, 3, 4)
+        D2T_BAND_CASE(151, 5, 1, 1, 16, 3, 4)
+        D2T_BAND_CASE(251, 5, 1, 2, 16, 3, 4)
+        D2T_BAND_CASE(142, 4, 2, 1, 16, 3, 4)
 #ifdef D2T_ENV_KNOBS                                                  /* scan builds (tools/band_scan.py) */
-        D2T_BAND_CASE(141, 4, 1, 32, 3, 2)
-        D2T_BAND_CASE(142, 4, 2, 32, 3, 2)
-        D2T_BAND_CASE(143, 4, 3, 32, 3, 2)
-        D2T_BAND_CASE(123, 2, 3, 32, 3, 2)
-        D2T_BAND_CASE(241, 4, 1, 16, 4, 1)
-        D2T_BAND_CASE(242, 4, 2, 16, 4, 1)
-        D2T_BAND_CASE(341, 4, 1, 16, 4, 4)
-        D2T_BAND_CASE(342, 4, 2, 16, 4, 4)
-        D2T_BAND_CASE(441, 4, 1, 16, 3, 2)
-        D2T_BAND_CASE(442, 4, 2, 16, 3, 2)
-        D2T_BAND_CASE(541, 4, 1, 32, 4, 2)
-        D2T_BAND_CASE(542, 4, 2, 32, 3, 4)
+        D2T_BAND_CASE(241, 4, 1, 2, 16, 3, 4)
+        D2T_BAND_CASE(1141, 4, 1, 1, 16, 3, 8)
+        D2T_BAND_CASE(1241, 4, 1, 2, 16, 3, 8)
+        D2T_BAND_CASE(1251, 5, 1, 2, 16, 3, 6)
+        D2T_BAND_CASE(161, 6, 1, 1, 16, 3, 4)
+        D2T_BAND_CASE(261, 6, 1, 2, 16, 3, 4)
+        D2T_BAND_CASE(131, 3, 1, 1, 16, 3, 4)
+        D2T_BAND_CASE(231, 3, 1, 2, 16, 3, 4)
+        D2T_BAND_CASE(123, 2, 3, 1, 16, 3, 4)
+        D2T_BAND_CASE(132, 3, 2, 1, 16, 3, 4)
+        D2T_BAND_CASE(232, 3, 2, 2, 16, 3, 4)
 #endif
 #undef D2T_BAND_CASE
         default: return D2T_EINVAL;
     }
 }
+
+#ifdef D2T_ENV_KNOBS
+extern "C" int d2t_lab_band_stamps(void* p)                          // scan builds: where the stamps go (NULL: off)
+{
+    unsigned long long* q = static_cast<unsigned long long*>(p);
+    return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(band_stamps), &q, sizeof(q)));
+}
+#endif
 
 }}  // namespace d2t::tuned

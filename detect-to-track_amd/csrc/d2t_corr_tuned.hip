@@ -98,9 +98,12 @@ struct BwdLevels { const float* gout[MAXLV]; const float* fm0[MAXLV]; const floa
 #ifndef D2T_EXP_EPI
 #define D2T_EXP_EPI 0      // tile-by-tile epilogue (round 4): measured 50.1 us against 47.5 us for the one-barrier form -- off
 #endif
+#ifndef D2T_FWD_LOADER
+#define D2T_FWD_LOADER 1   // round 5: a 16th wave issues every LDS-DMA instruction of the workgroup (A/B: make EXTRA=-DD2T_FWD_LOADER=0)
+#endif
 constexpr int SG_NU = 5;                            // p-tiles per segment
-constexpr int SG_WAVES = 15;                        // <= 30 (tile, tile-group) tasks, at most two per wave
-constexpr int SG_THREADS = SG_WAVES * 64;
+constexpr int SG_WAVES = 15;                        // computing waves: <= 30 (tile, tile-group) tasks, at most two per wave
+constexpr int SG_THREADS = (SG_WAVES + D2T_FWD_LOADER) * 64;
 constexpr int SG_KC = 16;                           // channels per staged chunk (4 k-steps)
 constexpr int SG_ROWS = 4 * SG_NU + 2 * DT - 1;     // 35 window rows of a segment
 constexpr int SG_SLOTS = SG_ROWS * NCG + 1;         // 176 slots of 16 bytes per channel (175 pieces + 1 pad)
@@ -182,9 +185,65 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     const int BPL = 4 * P;                                           // floats per channel plane
     const int a_base = SG_KC * BPL;                                  // float offset of the FM0 part in a buffer
     const int nBI = P >> 2;                                          // FM1 instructions per chunk (16 * P / 64)
-    const int ndma = nBI + SG_AI;
-    const int nd = (ndma - wave + SG_WAVES - 1) / SG_WAVES;          // this wave's instructions per chunk (wave-uniform)
+    const int ndma = nBI + SG_AI;                                    // LDS-DMA instructions per chunk
+    (void)ndma;
     const float rP = 1.0f / (float)P;
+    const int chunk_bytes = SG_KC * HW * 4;
+    using std::integral_constant;
+    typedef integral_constant<int, 0> K0; typedef integral_constant<int, 1> K1;
+    typedef integral_constant<int, 2> K2; typedef integral_constant<int, 3> K3;
+#if D2T_FWD_LOADER
+    // ---- the LOADER wave (wave 15): it issues all ndma LDS-DMA instructions of every chunk.  (Rounds 1-4 dealt them to the 15
+    // computing waves; a wave's stream is in order, the CU's address unit takes ~55 cycles per 1 KB instruction of 16-byte pieces
+    // -- csrc/d2t_corr_fwd_band.hip measured it with in-kernel clocks -- and every DMA a computing wave waits to issue is a slot
+    // in which it issues no MFMA: removing the DMA took 12 k cycles off a 67 k-cycle loop in round 2.)  One barrier per chunk for
+    // both roles; the loader arrives with `vmcnt(ndma)`: its instructions of chunk ch+1 have landed, chunk ch+2's are in flight.
+    if (wave == SG_WAVES) {
+        // addresses are recomputed per instruction (a dozen VALU operations against ~55 cycles of address-unit time each): no
+        // per-instruction register arrays, a loop of a few dozen instructions
+        auto stage = [&](int slot, int chunk) {
+            const int cb = chunk * chunk_bytes;
+            float* buf = smem + slot * SG_BUF;
+#pragma unroll 2
+            for (int k = 0; k < nBI; ++k) {                          // FM1: piece e of the [channel][row][column group] image lands in slot e
+                const int e = k * 64 + lane;
+                const int ch = (int)(((float)e + 0.5f) * rP), rem = e - ch * P;   // e / P, exact for e < 2^15
+                const int row = rem / NCG, cg = rem - row * NCG;
+                const int vo = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 + cb : OOR;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(buf + k * 256), 16, vo, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < SG_AI; ++k) {                        // FM0 pieces: (channel, pixel row of the segment)
+                const int e = k * 64 + lane;
+                const int ch = e / (4 * SG_NU), prow = e - ch * (4 * SG_NU);
+                const int i = 4 * u0 + prow;
+                const int vo = i < H ? (ch * HW + i * W + j0) * 4 + cb : OOR;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)(buf + a_base + k * 256), 16, vo, 0, 0, 0);
+            }
+        };
+        auto wait_prev_and_barrier = [&]() {                         // all but the youngest ndma instructions have landed
+            switch (nBI >> 2) {                                      // ndma = 4 (nBI / 4) + 5: nBI is a multiple of 4
+                case 1: dma_wait_barrier<9>(); break;   case 2: dma_wait_barrier<13>(); break;  case 3: dma_wait_barrier<17>(); break;
+                case 4: dma_wait_barrier<21>(); break;  case 5: dma_wait_barrier<25>(); break;  case 6: dma_wait_barrier<29>(); break;
+                case 7: dma_wait_barrier<33>(); break;  case 8: dma_wait_barrier<37>(); break;  case 9: dma_wait_barrier<41>(); break;
+                case 10: dma_wait_barrier<45>(); break; default: dma_wait_barrier<49>(); break;
+            }
+        };
+        const int nchunks_l = (C + SG_KC - 1) / SG_KC;
+        stage(0, 0);
+        stage(1, 1);
+        wait_prev_and_barrier();                                     // chunk 0 has landed
+        int s_fre = 2;
+        for (int ch = 0; ch < nchunks_l; ++ch) {
+            stage(s_fre, ch + 2);                                    // into the slot of chunk ch-1 (every wave is past its last read of it)
+            s_fre = s_fre == SG_RING - 1 ? 0 : s_fre + 1;
+            wait_prev_and_barrier();                                 // chunk ch+1 has landed; publish
+        }
+    }
+    auto dma = [&](int, int, auto) {};
+    auto wait_prev_chunk_and_barrier = [&]() { lds_barrier(); };
+#else
+    const int nd = (ndma - wave + SG_WAVES - 1) / SG_WAVES;          // this wave's instructions per chunk (wave-uniform)
     int dv[SG_MAXDMA], dl[SG_MAXDMA];                                // byte offset in the planes / float offset in the buffer
     bool dA[SG_MAXDMA];
 #pragma unroll
@@ -205,7 +264,6 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
             dl[k] = a_base + (y - nBI) * 256;
         }
     }
-    const int chunk_bytes = SG_KC * HW * 4;
     auto dma = [&](int slot, int chunk, auto k_c) {                  // this wave's k-th DMA instruction of `chunk` into ring slot `slot`
         constexpr int k = decltype(k_c)::value;
         if (k >= nd) return;                                         // wave-uniform
@@ -222,9 +280,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
         else if (nd == 1) dma_wait_barrier<1>();
         else dma_wait_barrier<0>();
     };
-    using std::integral_constant;
-    typedef integral_constant<int, 0> K0; typedef integral_constant<int, 1> K1;
-    typedef integral_constant<int, 2> K2; typedef integral_constant<int, 3> K3;
+#endif
     // chunk 0 goes out before anything else is computed; chunk 1 behind the task tables (every workgroup
     // of the chip starts at the same moment: chunk 0 alone lands sooner than both together)
     dma(0, 0, K0{}); dma(0, 0, K1{}); dma(0, 0, K2{}); dma(0, 0, K3{});
@@ -248,7 +304,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
 #pragma unroll
         for (int tt = 0; tt < SG_NU; ++tt)
             if (t == tt && q >= tgs[tt]) { q -= tgs[tt]; ++t; }
-        t_on[k] = t < SG_NU;                                          // q < tgs[t]
+        t_on[k] = t < SG_NU && wave < SG_WAVES;                       // q < tgs[t]; the loader wave has no task
         t = t_on[k] ? t : 0;
         const int T = t_on[k] ? q : 0;
         const int u = u0 + t;
@@ -330,9 +386,11 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
             s_cur = s_nxt;
         }
     };
-    if (t_on[1]) run(integral_constant<int, 2>{});                   // wave-uniform
-    else if (t_on[0]) run(integral_constant<int, 1>{});
-    else run(integral_constant<int, 0>{});
+    if (wave < SG_WAVES) {                                           // (the loader wave has met the same barriers in its own loop)
+        if (t_on[1]) run(integral_constant<int, 2>{});               // wave-uniform
+        else if (t_on[0]) run(integral_constant<int, 1>{});
+        else run(integral_constant<int, 0>{});
+    }
     D2T_STAMP(2);
 #ifdef D2T_LAB
     if (threadIdx.x == 0) { lab_stamps[blockIdx.x * 32 + 13] = lab_dma_wait; lab_stamps[blockIdx.x * 32 + 14] = lab_bar_wait; }

@@ -1129,6 +1129,208 @@ static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* g
     return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------
+// PSROIPool backward, ROW form (round 5): the GEMM above without its three pre-passes.  ONE launch produces the planes, the
+// gather adds them up.  Workgroup = task (cell row i, map row y), 7 waves, wave j = bin (i, j):
+//   1. all 448 threads scan the RoIs (one bin axis each: the cell row's extent, ps_roipool_cuda.cu:45-50) and compact
+//      the ones whose cell row i contains y into an LDS hit list, ascending (what k_ps_pairlists wrote to memory, with
+//      the seven column axes evaluated for EVERY RoI);
+//   2. per chunk of 32 hits: 224 threads evaluate the seven column axes of the hits and 1 / n; the others fetch the
+//      hits' gradOut runs gradOut[r][t][i][0..6] -- 28 contiguous bytes per target, so every fetched line is used for
+//      all seven bins (what k_ps_transpose_t re-laid memory for) -- into LDS as A[j][hit][target]; next chunk's loads
+//      are issued before this chunk's MFMAs;
+//   3. wave j: D_j[t][x] += A_j[t][hit] * B_j[hit][x] with B = 1 / n inside the cell's columns, 0 outside
+//      (v_mfma_f32_16x16x4_f32: M = targets, N = 16 map columns, K = 4 hits; a column tile no hit reaches is skipped).
+// Every plane row is written once as an ascending-RoI chain fma(gradOut, 1 / n, acc): deterministic; <= 1 ulp per term
+// from the reference's gradOut / n (its atomics leave the order open).  Measured R = 300 nT = 21: 31 -> __ us;
+// R = 3000 nT = 4: 59 -> __ us; R = 3000 nT = 31: 72 -> __ us.
+// ---------------------------------------------------------------------------------------
+constexpr int PR_WAVES = KT, PR_THREADS = PR_WAVES * 64;             // 448
+constexpr int PR_EC = 32;                                            // hits per chunk = 8 k-steps
+constexpr int PR_TP = 32;                                            // targets padded to two c-tiles
+constexpr int PR_MAXHITS = 4096;                                     // LDS hit list (ints); more hits: further rounds
+
+template <int XT, int NCT>
+__global__ void __launch_bounds__(PR_THREADS)
+k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ part, int R, int nT, int H, int W)
+{
+    __shared__ int hits[PR_MAXHITS];
+    __shared__ int wsum[PR_WAVES + 1];
+    __shared__ __attribute__((aligned(16))) float A[2][KT][PR_EC][PR_TP];   // 2 x 28 KB
+    __shared__ int ejb[2][PR_EC][KT + 1];
+    __shared__ float esc[2][PR_EC][KT + 1];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // one task per workgroup, numbered from the middle rows outwards: they carry the most hits and start first
+    const int task = blockIdx.x, p = task / KT, i = task - p * KT, d = (p + 1) >> 1;
+    const int y = (p & 1) ? (H - 1) / 2 + d : (H - 1) / 2 - d;
+    const int j = wave;                                              // this wave's bin column
+    const int bin = i * KT + j;
+    f32x4 acc[NCT][XT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int x = 0; x < XT; ++x) acc[ct][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned gout_bytes = (unsigned)((size_t)R * nT * KK * 4);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, gout_bytes, 0x00020000);
+
+    for (int rbase = 0; rbase < R; rbase += PR_MAXHITS) {            // one round unless more than 4096 RoIs
+        const int rend = R - rbase < PR_MAXHITS ? R : rbase + PR_MAXHITS;
+        // ---- 1. hit list of RoIs [rbase, rend): ascending
+        int total = 0;                                               // uniform
+        for (int r0 = rbase; r0 < rend; r0 += PR_THREADS) {
+            const int r = r0 + tid;
+            bool in = false;
+            if (r < rend) {
+                const float rI = rois[4 * (size_t)r], rH = rois[4 * (size_t)r + 2];
+                int i0, i1;
+                bin_axis<float>(rI - rH / 2.0f, rH / static_cast<float>(KT), i, H, i0, i1);
+                in = y >= i0 && y < i1;
+            }
+            const unsigned long long m = __ballot(in);
+            const int below = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            __syncthreads();                                         // wsum of the previous pass consumed
+            if (lane == 0) wsum[wave] = __builtin_popcountll(m);
+            __syncthreads();
+            int base = 0, cnt = 0;
+#pragma unroll
+            for (int w = 0; w < PR_WAVES; ++w) { const int v = wsum[w]; base += w < wave ? v : 0; cnt += v; }
+            if (in) hits[total + base + below] = r;
+            total += cnt;
+        }
+        __syncthreads();
+        // ---- 2 + 3. chunks of 32 hits
+        const int nchunk = (total + PR_EC - 1) / PR_EC;
+        // what this thread stages per chunk: (hit e, bin column q) geometry for tid < 224; (hit, target) runs for all
+        constexpr int NRUN = (PR_EC * PR_TP + PR_THREADS - 1) / PR_THREADS;   // 3
+        float run[NRUN][KT];
+        int gjb = 0; float gsc = 0.f;
+        auto load_chunk = [&](int c) {                               // global -> registers
+            const int e0 = c * PR_EC;
+            if (tid < PR_EC * KT) {
+                const int e = tid / KT, q = tid - e * KT;
+                gjb = 0; gsc = 0.f;
+                if (e0 + e < total) {
+                    const float* roi = rois + 4 * (size_t)hits[e0 + e];
+                    const Bounds cb = psroi_cell<float>(roi, i, q, H, W, KT);
+                    const int nn = (cb.i1 - cb.i0) * (cb.j1 - cb.j0);
+                    gjb = cb.j0 | (cb.j1 << 16);
+                    gsc = cb.i1 > cb.i0 && cb.j1 > cb.j0 ? 1.0f / static_cast<float>(nn) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NRUN; ++k) {
+                const int pr = tid + k * PR_THREADS, e = pr / PR_TP, t = pr - e * PR_TP;
+                const bool on = pr < PR_EC * PR_TP && e0 + e < total && t < nT;
+                const int off = on ? ((hits[e0 + (on ? e : 0)] * nT + t) * KK + i * KT) * 4 : 0x7ffffff0;   // out of range: zeros
+#pragma unroll
+                for (int q = 0; q < KT; ++q)
+                    run[k][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off, q * 4, 0));
+            }
+        };
+        auto store_chunk = [&](int buf) {                            // registers -> LDS
+            if (tid < PR_EC * KT) {
+                const int e = tid / KT, q = tid - e * KT;
+                ejb[buf][e][q] = gjb; esc[buf][e][q] = gsc;
+            }
+#pragma unroll
+            for (int k = 0; k < NRUN; ++k) {
+                const int pr = tid + k * PR_THREADS, e = pr / PR_TP, t = pr - e * PR_TP;
+                if (pr < PR_EC * PR_TP) {
+#pragma unroll
+                    for (int q = 0; q < KT; ++q) A[buf][q][e][t] = run[k][q];
+                }
+            }
+        };
+        if (nchunk > 0) { load_chunk(0); store_chunk(0); }
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunk) load_chunk(c + 1);                   // in flight under the MFMAs
+            const int ne = total - c * PR_EC < PR_EC ? total - c * PR_EC : PR_EC;
+#pragma unroll 2
+            for (int ks = 0; ks < PR_EC / 4; ++ks) {
+                if (4 * ks >= ne) break;                             // uniform
+                const int e = 4 * ks + g;
+                const int jb = ejb[buf][e][j];
+                const float sc = esc[buf][e][j];
+                const int j0 = jb & 0xffff, j1 = jb >> 16;
+                float a[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) a[ct] = A[buf][j][e][16 * ct + n];
+#pragma unroll
+                for (int x = 0; x < XT; ++x) {
+                    const int col = 16 * x + n;
+                    const float b = col >= j0 && col < j1 ? sc : 0.f;
+                    if (!__builtin_amdgcn_ballot_w64(b != 0.f)) continue;   // no hit of this k-step reaches the column tile
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], b, acc[ct][x], 0, 0, 0);
+                }
+            }
+            if (c + 1 < nchunk) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // ---- planes: D[m = target 16 ct + 4 g + r][n = column 16 x + n]
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int x = 0; x < XT; ++x) {
+            const f32x4 v = acc[ct][x];
+            const int col = 16 * x + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * ct + 4 * g + r;
+                if (t < nT && col < W) part[(((size_t)t * KK + bin) * H + y) * W + col] = v[r];
+            }
+            // Cold path, as in k_roipool_bwd_gemm: a non-finite gradOut value times a 0 weight poisons columns outside its cell
+            // (the reference, ps_roipool_cuda.cu:131-139, only adds to the cell's own pixels); the wave recomputes the 16 x 16
+            // tile it stored with exact membership from the RoIs themselves.
+            if (__builtin_expect(__any(pool_nonfinite4(v)), 0)) {
+                for (int e = lane; e < 256; e += 64) {
+                    const int t = 16 * ct + (e >> 4), xx = 16 * x + (e & 15);
+                    if (t >= nT || xx >= W) continue;
+                    float a = 0.f;
+                    for (int r = 0; r < R; ++r) {
+                        const Bounds cb = psroi_cell<float>(rois + 4 * (size_t)r, i, j, H, W, KT);
+                        const int nn = (cb.i1 - cb.i0) * (cb.j1 - cb.j0);
+                        if (y >= cb.i0 && y < cb.i1 && xx >= cb.j0 && xx < cb.j1)
+                            a = __builtin_fmaf(gout[((size_t)r * nT + t) * KK + bin], 1.0f / static_cast<float>(nn), a);
+                    }
+                    part[(((size_t)t * KK + bin) * H + y) * W + xx] = a;
+                }
+            }
+        }
+}
+
+static bool psroipool_bwd_rows_supported(int R, int nT, int H, int W, int k)
+{
+    return k == KT && R >= 1 && nT >= 1 && nT <= PR_TP && H >= 1 && H <= 65535 && W >= 1 && W <= 128 &&
+           1LL * R * nT * KK * 4 < 0x7ffffff0LL && 1LL * nT * KK * H * W < 0x7fffffffLL && 1LL * KT * H < 0x7fffffffLL;
+}
+
+// workspace: planes (nT*49, H*W)
+static size_t psroipool_bwd_rows_ws_bytes(int R, int nT, int H, int W, int k)
+{
+    return psroipool_bwd_rows_supported(R, nT, H, W, k) ? align256((size_t)nT * KK * H * W * 4) : 0;
+}
+
+static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, void* ws, hipStream_t st)
+{
+    float* part = static_cast<float*>(ws);
+    const int xt = (W + 15) / 16, ntasks = KT * H;
+#define D2T_LAUNCH_PR(XTV, NCTV) hipLaunchKernelGGL((k_ps_bwd_rows<XTV, NCTV>), dim3(ntasks), dim3(PR_THREADS), 0, st, gout, rois, part, R, nT, H, W)
+#define D2T_LAUNCH_PR_X(NCTV) { if (xt <= 4) D2T_LAUNCH_PR(4, NCTV); else if (xt <= 5) D2T_LAUNCH_PR(5, NCTV); else D2T_LAUNCH_PR(8, NCTV); }
+    if (nT <= 16) D2T_LAUNCH_PR_X(1) else D2T_LAUNCH_PR_X(2)
+#undef D2T_LAUNCH_PR_X
+#undef D2T_LAUNCH_PR
+    int rc = launch_status();
+    if (rc != D2T_OK) return rc;
+    const int HW = H * W;
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
+    return launch_status();
+}
+
 // Which of the three backward designs runs (ps_bwd_design below).  History of the sorted lists vs the planes:
 // the sorted-corner-list kernels (d2t_pool_sorted.hip) do
 // work proportional to the RoI corners per plane (4R) plus a fixed cost of three launches and a
@@ -1145,23 +1347,25 @@ static int ps_bwd_forced()
     static const int v = [] {
         const char* e = lab_env_str("D2T_PS_BWD");                       // -DD2T_LAB only
         if (!e) return 0;
-        return !strcmp(e, "planes") ? 1 : !strcmp(e, "sorted") ? 2 : !strcmp(e, "gemm") ? 3 : 0;
+        return !strcmp(e, "planes") ? 1 : !strcmp(e, "sorted") ? 2 : !strcmp(e, "gemm") ? 3 : !strcmp(e, "rows") ? 4 : 0;
     }();
     return v;
 }
 
-// 0 = plane kernels, 1 = sorted corner lists, 2 = GEMM
+// 0 = plane kernels, 1 = sorted corner lists, 2 = GEMM behind three pre-passes, 3 = row form (one launch + gather)
 static int ps_bwd_design(int R, int nT, int H, int W, int k)
 {
     const bool g = psroipool_bwd_gemm_supported(R, nT, H, W, k), s = psroipool_bwd_sorted_supported(R, nT, H, W, k),
-               p = psroipool_bwd_planes_supported(R, nT, H, W, k);
+               p = psroipool_bwd_planes_supported(R, nT, H, W, k), rw = psroipool_bwd_rows_supported(R, nT, H, W, k);
     const int f = ps_bwd_forced();
+    if (f == 4 && rw) return 3;
     if (f == 3 && g) return 2;
     if (f == 2 && s) return 1;
     if (f == 1 && p) return 0;
     // measured grid R in {300..3000} x nT in {4..31} on a 38x75 map (tools/ps_scan.py, profiles/r02_b_ps_bwd_scan_*):
     // the GEMM wins from 12 targets up at every R (R=300 nT=16: 33 vs 40 us; R=3000 nT=31: 73 vs 148 sorted / 278 planes)
     // and from 8 targets at R >= 1000; the plane kernels keep the small shapes (R=300 nT=4: 15 vs 25 us)
+    if (rw && f == 0) return 3;                                       // round 5: the row form takes every shape it supports
     if (g && (nT >= 12 || (nT >= 8 && R >= 1000) || !p)) return 2;
     if (s && (!p || (nT >= PS_SORTED_MIN_TARGETS && 1LL * R * nT >= PS_SORTED_MIN_WORK))) return 1;
     return p ? 0 : (s ? 1 : 0);
@@ -1169,13 +1373,14 @@ static int ps_bwd_design(int R, int nT, int H, int W, int k)
 
 bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
 {
-    return psroipool_bwd_gemm_supported(R, nT, H, W, k) || psroipool_bwd_sorted_supported(R, nT, H, W, k) ||
-           psroipool_bwd_planes_supported(R, nT, H, W, k);
+    return psroipool_bwd_rows_supported(R, nT, H, W, k) || psroipool_bwd_gemm_supported(R, nT, H, W, k) ||
+           psroipool_bwd_sorted_supported(R, nT, H, W, k) || psroipool_bwd_planes_supported(R, nT, H, W, k);
 }
 
 size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
 {
     const int d = ps_bwd_design(R, nT, H, W, k);
+    if (d == 3) return psroipool_bwd_rows_ws_bytes(R, nT, H, W, k);
     return d == 2 ? psroipool_bwd_gemm_ws_bytes(R, nT, H, W, k) : d == 1 ? psroipool_bwd_sorted_ws_bytes(R, nT, H, W, k)
                                                                          : psroipool_bwd_planes_ws_bytes(R, nT, H, W, k);
 }
@@ -1184,6 +1389,7 @@ int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, i
                       void* ws, hipStream_t st)
 {
     const int d = ps_bwd_design(R, nT, H, W, k);
+    if (d == 3) return psroipool_bwd_rows_f32(gout, rois, gin, R, nT, H, W, ws, st);
     if (d == 2) return psroipool_bwd_gemm_f32(gout, rois, gin, R, nT, H, W, ws, st);
     if (d == 1) return psroipool_bwd_sorted_f32(gout, rois, gin, R, nT, H, W, k, ws, st);
     return psroipool_bwd_planes_f32(gout, rois, gin, R, nT, H, W, k, ws, st);

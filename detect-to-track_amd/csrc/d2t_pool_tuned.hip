@@ -27,6 +27,7 @@
 
 namespace d2t { namespace tuned {
 
+D2T_KSTAMP_DEFINE(d2t_lab_pool_fwd_stamps)
 
 // ---------------------------------------------------------------------------------------
 // (rows, cols) -> (cols, rows) transpose of a row-major f32 matrix, 32x32 tiles through LDS;
@@ -219,6 +220,7 @@ k_roipool_fwd_sat2(const float* __restrict__ fm, const float* __restrict__ rois,
     const int tid = threadIdx.x, HW = H * W;
     const int c0 = blockIdx.x * 2;
     const int r_lo = blockIdx.y * rois_per_wg, r_hi = r_lo + rois_per_wg < R ? r_lo + rois_per_wg : R;
+    D2T_KSTAMP(0);
 
     for (int e = tid; e < 2 * (H + 1); e += S2_THREADS) sat[(size_t)(e >> 1) * LD * 2 + (e & 1)] = 0.0;   // column 0
     for (int e = tid; e < 2 * LD; e += S2_THREADS) sat[e] = 0.0;                                           // row 0
@@ -243,7 +245,9 @@ k_roipool_fwd_sat2(const float* __restrict__ fm, const float* __restrict__ rois,
         }
     }
     __syncthreads();
+    D2T_KSTAMP(1);
     prefix2d(sat + (size_t)(LD + 1) * 2, scr, 2, H, W, LD, 1, tid, S2_THREADS, 2);
+    D2T_KSTAMP(2);
 
     // ---- outputs: thread t < 980 owns bin t mod 49 of RoI slot t / 49 (20 RoIs per pass), both channels
     const int RPP = KTT ? S2_ACTIVE / KK : S2_THREADS / kk;          // RoIs per pass
@@ -264,6 +268,7 @@ k_roipool_fwd_sat2(const float* __restrict__ fm, const float* __restrict__ rois,
             *reinterpret_cast<unsigned short*>(geoW + rr * geo + 2 * kt + 2 * qq) = (unsigned short)(bq.j0 | (bq.j1 << 8));
         }
         __syncthreads();
+        D2T_KSTAMP(rb == r_lo ? 3 : 5);
         if (!live0) continue;
         float* dst = out + ((size_t)(rb + rr0) * C + c0) * kk + bin;
         const size_t dstep = (size_t)RPP * C * kk;
@@ -296,7 +301,9 @@ k_roipool_fwd_sat2(const float* __restrict__ fm, const float* __restrict__ rois,
             pool(rr, dst, true);
             pool(rr + RPP, dst + dstep, rr + RPP < rc);
         }
+        D2T_KSTAMP(rb == r_lo ? 4 : 6);
     }
+    D2T_KSTAMP(7);
 }
 
 static int sat_cg(int C, int H, int W)

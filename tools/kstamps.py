@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""In-kernel clock reads (knob build, -DD2T_ENV_KNOBS) of the pooling kernels: where a workgroup's time goes.
+    D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 tools/kstamps.py roipool_fwd"""
+import ctypes
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
+from detect_to_track.models import _native  # noqa: E402
+import bench_ops  # noqa: E402
+
+lib, dev = _native.lib, "cuda:0"
+NWG = 16384
+
+
+def run(setter, call, names):
+    fn = getattr(lib, setter)
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    stamps = torch.zeros(NWG, 16, dtype=torch.int64, device=dev)
+    for it in range(3):
+        assert fn(stamps.data_ptr() if it == 2 else None) == 0
+        stamps.zero_()
+        torch.cuda.synchronize()
+        call()
+        torch.cuda.synchronize()
+    assert fn(None) == 0
+    s = stamps.cpu().numpy()
+    s = s[s[:, 0] != 0]
+    print(f"{len(s)} workgroups stamped; first entry -> last stamp {(s.max() - s[:, 0].min())} cycles")
+    for i in range(1, len(names)):
+        on = (s[:, i] != 0) & (s[:, i - 1] != 0)
+        if on.any():
+            d = s[on, i] - s[on, i - 1]
+            print(f"   {names[i - 1]:28s} -> {names[i]:28s}: median {np.median(d):8.0f}  max {d.max():8d}  ({on.sum()} WGs)")
+    last = np.max(s[:, 1:len(names)], axis=1)
+    print(f"   workgroup lifetime: median {np.median(last - s[:, 0]):.0f} max {(last - s[:, 0]).max()} cycles; entry skew {s[:, 0].max() - s[:, 0].min()}")
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "roipool_fwd"
+    st = torch.cuda.current_stream().cuda_stream
+    if what == "roipool_fwd":
+        R, C, H, W, K = 300, 1024, 38, 63, 7
+        fm, out = torch.rand(C, H, W, device=dev), torch.empty(R, C, K, K, device=dev)
+        rois = torch.from_numpy(bench_ops.random_rois(R, 0)).to(dev)
+        run("d2t_lab_pool_fwd_stamps",
+            lambda: bench_ops._check(lib.d2t_roipool_fwd_f32(fm.data_ptr(), rois.data_ptr(), out.data_ptr(), R, C, H, W, K, 0, 0, 0, st)),
+            ["entry", "planes in LDS", "prefix2d done", "geometry 1 done", "look-ups 1 done", "geometry 2 done", "look-ups 2 done", "end"])
+
+
+if __name__ == "__main__":
+    main()
