@@ -139,9 +139,24 @@ inline const char* lab_env_str(const char*) { return nullptr; }
             kstamps_[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_;                  \
         }                                                                                             \
     } while (0)
+#define D2T_KSTAMP_RT(i)                                                                              \
+    do {                                                                                              \
+        if (kstamps_ && threadIdx.x == 0) {                                                           \
+            unsigned long long t_;                                                                    \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+            kstamps_[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_;                  \
+        }                                                                                             \
+    } while (0)
+#define D2T_KCLK(var) do { if (kstamps_) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); } while (0)
+#define D2T_KSTAMP_PUT(i, val) do { if (kstamps_ && threadIdx.x == 0) kstamps_[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = (val); } while (0)
+#define D2T_KSTAMP_ONLY(...) __VA_ARGS__
 #else
 #define D2T_KSTAMP_DEFINE(setter)
 #define D2T_KSTAMP(i)
+#define D2T_KSTAMP_RT(i)
+#define D2T_KCLK(var)
+#define D2T_KSTAMP_PUT(i, val)
+#define D2T_KSTAMP_ONLY(...)
 #endif
 
 inline bool fits_i32(long long v) { return v >= 0 && v <= 2147483647LL; }

@@ -5,26 +5,35 @@
 //
 // Why a second forward.  A 4 x 4 p-tile has 6 tile-groups (16 window slot groups = 4 N-tiles each); 190 tiles at 38 x 75
 // are 1,140 (tile, tile-group) TASKS of 16 MFMAs per 16 channels.  The one-tile-per-workgroup kernel
-// (k_corr_fwd_segx<1,4,true>) gives a CU all 6 tasks of a tile and leaves 66 CUs idle; its time is the L1-miss path of ONE
-// CU streaming a 19 x 20 window per 16 channels (34.6 cache lines per channel: notebook 4.2-6) -- 0.92 us per chunk where
-// the matrix work is 0.32 us.  Here a workgroup is
+// (k_corr_fwd_segx<1,4,true>, rounds 1-4) gave a CU all 6 tasks of a tile and left 66 CUs idle; its time was the L1-miss
+// path of ONE CU streaming a 19 x 20 window per 16 channels -- 0.92 us per chunk where the matrix work is 0.32 us.
+// Here a workgroup is
 //     (tile row u, block of TW tiles side by side, band-set q of NB consecutive tile-groups)
-// with ONE task per wave (TW * NB waves): the block's window is 4 TW + 16 columns wide, so a window row is one 96 / 128
-// byte run for 2 / 4 tiles instead of 80 bytes per tile, a band-set needs only its own 4 / 7 / 10 window rows, and the
-// FM0 pixels of the block are staged once for its NB bands.  Lines per channel and task: 5.8 (one tile, all bands) ->
-// 3.5 (TW 4, NB 1), 2.5 (TW 4, NB 2); tasks per SIMD: 1 or 2 instead of 1.5 on three quarters of the chip.
+// with one task per wave (or two waves per task, HT = 2, each multiplying two of its four N-tiles): the block's window
+// is 4 TW + 16 columns wide, so a window row is ONE run of 128 / 144 bytes for 4 / 5 tiles instead of 80 bytes per tile,
+// a band-set needs only its own 4 / 7 window rows, and TW is chosen so that the grid is ONE workgroup per CU (38 x 63:
+// TW 4 -> 240 workgroups; 38 x 75: TW 5 -> 240).
 //
-// Staging and loop are those of k_corr_fwd_segx (ring of chunk images filled by LDS-DMA, counted vmcnt waits, one
-// barrier per chunk, the next chunk's fragments fetched under this chunk's MFMAs).  The epilogue stores straight from
-// the accumulators: a band's cells of a pixel are a contiguous run of its 17 x 17 block, so no LDS staging, no barrier;
-// the structural zeros (cj = 16, ci = 16, displaced columns outside the map) are written by the lanes that own those
-// slots, window rows outside the map ("orphan rows") by the first / last band-set of the tile row.
+// What the in-kernel clocks said on the way (tools/band_stamps.py, profiles/r05_*_band_stamps.txt):
+//   * the CU's address unit takes ~55 cycles per LDS-DMA instruction of 64 x 16 bytes whatever wave issues it, and a
+//     wave that waits to issue one issues no MFMA: with the DMA dealt to the computing waves a chunk took 0.61 us
+//     where the matrix work is 0.43 us.  So WL dedicated LOADER waves issue every DMA instruction; the computing
+//     waves' stream is LDS reads and MFMAs only.  (4-byte-per-lane DMA -- 256 contiguous bytes per instruction -- is
+//     no cheaper per instruction: 2.4x slower in all.)
+//   * code that runs once per wave is not free: a straight-from-the-registers epilogue (12-16 exec-masked stores, 4 KB
+//     of straight-line code fetched cold by every wave of the chip at the same moment) took 4.3 k cycles of a 30 k-cycle
+//     kernel.  The epilogue is a scatter into a per-task LDS patch and a short store loop.
+// Staging: ring of RING chunk images filled by LDS-DMA, counted vmcnt waits on the loader side, ONE barrier per chunk
+// for both roles, placed in the middle of a chunk's MFMAs so that the next chunk's fragments are fetched under its
+// second half.  A band's cells of a pixel are a contiguous run of its 17 x 17 block; the structural zeros (cj = 16,
+// ci = 16, displaced columns outside the map) are written by the lanes that own those slots, window rows outside the
+// map ("orphan rows") by the first / last band-set of the tile row.
 #include "d2t_corr_common.hpp"
 
 namespace d2t { namespace tuned {
 
-#ifdef D2T_ENV_KNOBS
-// in-kernel stamps of the scan build (tools/band_scan.py --stamps): [workgroup][16] clock reads of compute wave 0 (0-4) and of the first
+#ifdef D2T_BAND_STAMPS
+// in-kernel stamps of the stamp build (-DD2T_ENV_KNOBS -DD2T_BAND_STAMPS) (tools/band_scan.py --stamps): [workgroup][16] clock reads of compute wave 0 (0-4) and of the first
 // loader wave (8-13), s_memrealtime at entry / exit (14, 15).  The product library is built without D2T_ENV_KNOBS: no stamp executes there.
 __device__ unsigned long long* band_stamps;
 #define BAND_STAMP(cond, i)                                                                           \
@@ -195,7 +204,7 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
 #pragma unroll
         for (int p = 1; p < RING - 1; ++p) stage(p, p);              // chunks 1 .. RING-2 go out under the first MFMAs
         int slot = RING - 1;                                         // where chunk ch + RING - 1 goes
-#ifdef D2T_ENV_KNOBS
+#ifdef D2T_BAND_STAMPS
         unsigned long long t_issue = 0, t_wait = 0, ta_, tb_, tc_;
 #endif
         for (int ch = 0; ch < nchunks; ++ch) {
@@ -204,12 +213,12 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
             BAND_CLK(tb_);
             slot = slot + 1 == RING ? 0 : slot + 1;
             dma_wait_barrier<S::INFLIGHT>();                         // barrier #(ch+1): chunk ch+1 has landed
-#ifdef D2T_ENV_KNOBS
+#ifdef D2T_BAND_STAMPS
             BAND_CLK(tc_); t_issue += tb_ - ta_; t_wait += tc_ - tb_;
 #endif
         }
         BAND_STAMP(lw == 0, 11);
-#ifdef D2T_ENV_KNOBS
+#ifdef D2T_BAND_STAMPS
         if (band_stamps && lw == 0 && lane == 0) { band_stamps[(size_t)blockIdx.x * 16 + 12] = t_issue; band_stamps[(size_t)blockIdx.x * 16 + 13] = t_wait; }
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the parked instructions staged past the end
@@ -253,10 +262,52 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     // zeros (cj = 16, ci = 16, displaced columns outside the map) included -- and the task's waves store the runs with consecutive
     // lanes on consecutive cells.  (Straight from the registers, as at first: 12-16 exec-masked store instructions per wave, each
     // touching a dozen lines -- and 4 KB of straight-line code that every wave of the chip fetched cold at the same moment.)
+    const int gf = 16 * T, gl = (gf + 15 < ng ? gf + 15 : ng - 1);   // the task's first / last group (wave-uniform)
+    if (HT == 1 && lay.cs == 1) {
+        // Reference layout, one wave per task: straight from the accumulators.  The four s of a lane are adjacent cells, so a lane
+        // stores ONE run per pixel -- 16 bytes for the inner column groups, the part inside [0, 16] for the first and the last one.
+        // (A vector-memory instruction costs its wave ~15 cycles per line it touches: the 16 dword stores of the first version and
+        // these 12 take the same 4 k cycles; an LDS patch + store loop with consecutive lanes on consecutive cells touches a
+        // quarter of the lines but took 11.8 k cycles in loop overhead -- profiles/r05_b_band_stamps_*.txt.)
+        const int i = 4 * u + g, ci = rho - i + DT;
+        if (lane_on && i < H && ci >= 0 && ci <= 2 * DT) {
+            const int jt = j0 + 4 * v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt + r;
+                if (j < W) {
+                    unsigned val[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int cj = 4 * cg + s - r, dj = j + cj - DT;
+                        val[s] = __builtin_bit_cast(unsigned, ci < 2 * DT && cj < 2 * DT && dj >= 0 && dj < W ? acc[s % S::NS][r] : 0.f);
+                    }
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+                    const int base = ((i * W + j) * CELLS + ci * CW + 4 * cg - r) * 4;   // byte offset of cell cj = 4 cg - r (s = 0)
+                    if (cg >= 1 && cg <= 3) {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{val[0], val[1], val[2], val[3]}, ro, base, 0, 0);
+                    } else if (cg == 0) {                            // cells cj = s - r >= 0: s = r .. 3
+                        if (r == 0) __builtin_amdgcn_raw_buffer_store_b128(u32x4{val[0], val[1], val[2], val[3]}, ro, base, 0, 0);
+                        else if (r == 1) __builtin_amdgcn_raw_buffer_store_b96(u32x3{val[1], val[2], val[3]}, ro, base + 4, 0, 0);
+                        else if (r == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{val[2], val[3]}, ro, base + 8, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b32(val[3], ro, base + 12, 0, 0);
+                    } else {                                         // cg = 4: cells cj = 16 - r + s <= 16: s = 0 .. r
+                        if (r == 0) __builtin_amdgcn_raw_buffer_store_b32(val[0], ro, base, 0, 0);
+                        else if (r == 1) __builtin_amdgcn_raw_buffer_store_b64(u32x2{val[0], val[1]}, ro, base, 0, 0);
+                        else if (r == 2) __builtin_amdgcn_raw_buffer_store_b96(u32x3{val[0], val[1], val[2]}, ro, base, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(u32x4{val[0], val[1], val[2], val[3]}, ro, base, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
+    // Two waves per task, or the channel-major layout: through LDS.  A task's cells of a pixel are ONE contiguous run of its 17 x 17
+    // block, so its waves scatter their accumulators into the task's patch [16 pixels][PATCH] -- structural zeros included -- and
+    // the runs are stored from there.
     __syncthreads();                                                 // every wave is past its last read of the ring; the ring is quiet
     BAND_STAMP(wave == 0, 5);
-    const int gf = 16 * T, gl = (gf + 15 < ng ? gf + 15 : ng - 1);   // the task's first / last group (wave-uniform)
-    const int rho_f = wa + gf / NCG, cg_f = gf - (gf / NCG) * NCG, rho_l = wa + gl / NCG, cg_l = gl - (gl / NCG) * NCG;
+    const int rho_f = wa + gf / NCG;                                 // first window row of the task: patch index k = (rho - rho_f) * 17 + cj
     float* patch = smem + task * 16 * PATCH;
     if (lane_on) {
         const int i = 4 * u + g, ci = rho - i + DT;
@@ -272,22 +323,49 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
             }
         }
     }
-    if (HT > 1) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // HT = 1: the patch is the wave's own
-    if (t_on) {
-        // pixel p = (row pg, column pr) of the tile: its run is patch[p][kA .. kB]; cell index in the pixel's block = fb + k
-        for (int e = hs * 64 + lane; e < 16 * PATCH; e += 64 * HT) {
-            const int p = e / PATCH, k = e - p * PATCH;
-            const int pg = p >> 2, pr = p & 3;
-            const int i = 4 * u + pg, j = j0 + 4 * v + pr;
-            const int rlo = rho_f > i - DT ? rho_f : i - DT, rhi = rho_l < i + DT ? rho_l : i + DT;
-            int cjA = 4 * cg_f - pr; cjA = rlo == rho_f && cjA > 0 ? cjA : 0;
-            int cjB = 4 * cg_l + 3 - pr; cjB = rhi == rho_l && cjB < 2 * DT ? cjB : 2 * DT;
-            const int kA = (rlo - rho_f) * CW + cjA, kB = (rhi - rho_f) * CW + cjB;
-            if (i < H && j < W && rlo <= rhi && k >= kA && k <= kB) {
-                const int cell = (rho_f - i + DT) * CW + k;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, patch[e]), ro, ((i * W + j) * lay.ps + cell * lay.cs) * 4, 0, 0);
+    // pixel p = (row pg, column pr) of a task's tile: its run is patch[p][kA .. kB]; cell index in the pixel's 17 x 17 block = fb + k
+    auto run_of = [&](int tgf, int tgl, int pg, int pr, int& kA, int& kB, int& fb) -> bool {
+        const int trf = wa + tgf / NCG, tcf = tgf - (tgf / NCG) * NCG, trl = wa + tgl / NCG, tcl = tgl - (tgl / NCG) * NCG;
+        const int pi = 4 * u + pg;
+        const int rlo = trf > pi - DT ? trf : pi - DT, rhi = trl < pi + DT ? trl : pi + DT;
+        int cjA = 4 * tcf - pr; cjA = rlo == trf && cjA > 0 ? cjA : 0;
+        int cjB = 4 * tcl + 3 - pr; cjB = rhi == trl && cjB < 2 * DT ? cjB : 2 * DT;
+        kA = (rlo - trf) * CW + cjA; kB = (rhi - trf) * CW + cjB;
+        fb = (trf - pi + DT) * CW;
+        return pi < H && rlo <= rhi;
+    };
+    if (lay.cs == 1) {
+        // reference layout: a pixel's cells are contiguous -- the task's own waves store its patch, consecutive lanes on consecutive cells
+        if (HT > 1) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // HT = 1: the patch is the wave's own
+        if (t_on) {
+            for (int e = hs * 64 + lane; e < 16 * PATCH; e += 64 * HT) {
+                const int p = e / PATCH, k = e - p * PATCH;
+                const int pj = j0 + 4 * v + (p & 3);
+                int kA, kB, fb;
+                if (run_of(gf, gl, p >> 2, p & 3, kA, kB, fb) && pj < W && k >= kA && k <= kB)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, patch[e]), ro,
+                                                          (((4 * u + (p >> 2)) * W + pj) * lay.ps + (fb + k) * lay.cs) * 4, 0, 0);
             }
         }
+    } else {
+        // channel-major (the tracker's concat buffer): cell c of pixel (i, j) at c * cs + (i * W + j) -- what is contiguous is a ROW OF
+        // PIXELS of one cell, so the whole workgroup walks (band, cell, pixel row, the block's 4 TW pixel columns) with consecutive
+        // threads on consecutive pixels: 16 TW contiguous bytes per (cell, pixel row) instead of one line per dword
+        __syncthreads();
+        for (int tb = 0; tb < NB; ++tb) {
+            const int tT = NB * q + tb;
+            if (16 * tT >= ng) break;                                // wave-uniform
+            const int tgf = 16 * tT, tgl = tgf + 15 < ng ? tgf + 15 : ng - 1;
+            for (int e = tid; e < PATCH * 4 * (4 * TW); e += S::THREADS) {
+                const int px = e % (4 * TW), rest = e / (4 * TW), pg = rest & 3, k = rest >> 2;
+                const int pv = px >> 2, pr = px & 3, pj = j0 + px;
+                int kA, kB, fb;
+                if (run_of(tgf, tgl, pg, pr, kA, kB, fb) && pj < W && k >= kA && k <= kB)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, smem[((tb * TW + pv) * 16 + 4 * pg + pr) * PATCH + k]), ro,
+                                                          (((4 * u + pg) * W + pj) * lay.ps + (fb + k) * lay.cs) * 4, 0, 0);
+            }
+        }
+    }
     }
     BAND_STAMP(wave == 0, 3);
     // orphan rows: cells whose displaced row lies outside the tile row's window -- above the map (first band-set: ci < d - i), below
@@ -310,7 +388,7 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
             }
         }
     }
-#ifdef D2T_ENV_KNOBS
+#ifdef D2T_BAND_STAMPS
     if (band_stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have been acknowledged
     BAND_STAMP(wave == 0, 4); BAND_STAMP_RT(wave == 0, 15);
 #endif
@@ -339,7 +417,11 @@ int corr_fwd_band_config(int B, int H, int W)
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     const long long tasks = 6LL * B * tiles_i * tiles_j;
     if (tasks > 2600) return 0;                                      // larger grids: the segment kernels of d2t_corr_tuned.hip
-    return 141;
+    // One workgroup per CU is what pays (profiles/r05_b_band_scan.txt, us): 38 x 63 -- 16 tile columns, TW 4: 240 workgroups -- B = 1 C = 256
+    // 11.8 (one-tile kernel 17.7); 38 x 75 -- 19 tile columns -- TW 4: 300 workgroups, 44 CUs carry two: C = 2048 83.6; TW 5 with two waves
+    // per task (10 computing + 6 loader waves): 240 workgroups, 69.0 (one-tile kernel 115).  Grids of several rounds (B = 2): TW 4.
+    const long long n4 = 6LL * B * tiles_i * ((tiles_j + 3) / 4), n5 = 6LL * B * tiles_i * ((tiles_j + 4) / 5);
+    return n4 > 256 && n5 <= 256 ? 1251 : 141;
 }
 
 int corr_fwd_band_f32(int cfg, const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, CellLayout lay, hipStream_t st)
@@ -347,28 +429,22 @@ int corr_fwd_band_f32(int cfg, const float* fm0, const float* fm1, float* out, i
     switch (cfg) {
 #define D2T_BAND_CASE(id, TW, NB, HT, KC, RING, WL) case id: return launch_band<TW, NB, HT, KC, RING, WL>(fm0, fm1, out, B, C, H, W, lay, st);
         D2T_BAND_CASE(141, 4, 1, 1, 16, 3, 4)
+        D2T_BAND_CASE(1251, 5, 1, 2, 16, 3, 6)
+#ifdef D2T_ENV_KNOBS                                                  /* scan builds (tools/band_scan.py) */
+        D2T_BAND_CASE(1141, 4, 1, 1, 16, 3, 8)
         D2T_BAND_CASE(151, 5, 1, 1, 16, 3, 4)
         D2T_BAND_CASE(251, 5, 1, 2, 16, 3, 4)
-        D2T_BAND_CASE(142, 4, 2, 1, 16, 3, 4)
-#ifdef D2T_ENV_KNOBS                                                  /* scan builds (tools/band_scan.py) */
         D2T_BAND_CASE(241, 4, 1, 2, 16, 3, 4)
-        D2T_BAND_CASE(1141, 4, 1, 1, 16, 3, 8)
-        D2T_BAND_CASE(1241, 4, 1, 2, 16, 3, 8)
-        D2T_BAND_CASE(1251, 5, 1, 2, 16, 3, 6)
-        D2T_BAND_CASE(161, 6, 1, 1, 16, 3, 4)
-        D2T_BAND_CASE(261, 6, 1, 2, 16, 3, 4)
         D2T_BAND_CASE(131, 3, 1, 1, 16, 3, 4)
-        D2T_BAND_CASE(231, 3, 1, 2, 16, 3, 4)
+        D2T_BAND_CASE(142, 4, 2, 1, 16, 3, 4)
         D2T_BAND_CASE(123, 2, 3, 1, 16, 3, 4)
-        D2T_BAND_CASE(132, 3, 2, 1, 16, 3, 4)
-        D2T_BAND_CASE(232, 3, 2, 2, 16, 3, 4)
 #endif
 #undef D2T_BAND_CASE
         default: return D2T_EINVAL;
     }
 }
 
-#ifdef D2T_ENV_KNOBS
+#ifdef D2T_BAND_STAMPS
 extern "C" int d2t_lab_band_stamps(void* p)                          // scan builds: where the stamps go (NULL: off)
 {
     unsigned long long* q = static_cast<unsigned long long*>(p);

@@ -99,7 +99,11 @@ struct BwdLevels { const float* gout[MAXLV]; const float* fm0[MAXLV]; const floa
 #define D2T_EXP_EPI 0      // tile-by-tile epilogue (round 4): measured 50.1 us against 47.5 us for the one-barrier form -- off
 #endif
 #ifndef D2T_FWD_LOADER
-#define D2T_FWD_LOADER 1   // round 5: a 16th wave issues every LDS-DMA instruction of the workgroup (A/B: make EXTRA=-DD2T_FWD_LOADER=0)
+#define D2T_FWD_LOADER 0   // round 5 experiment (make EXTRA=-DD2T_FWD_LOADER=1): ONE loader wave issues every LDS-DMA instruction -- 80.1 us against 47.2
+                           // (profiles/r05_a_ab_fwd_loader_wave.txt): a wave issues one such instruction per ~290 cycles, 41 per chunk take 5 us
+#endif
+#ifndef D2T_FWD_STAGGER
+#define D2T_FWD_STAGGER 1  // round 5: the waves of a SIMD issue their LDS-DMA instructions at different k-steps of a chunk (A/B: -DD2T_FWD_STAGGER=0)
 #endif
 constexpr int SG_NU = 5;                            // p-tiles per segment
 constexpr int SG_WAVES = 15;                        // computing waves: <= 30 (tile, tile-group) tasks, at most two per wave
@@ -333,6 +337,8 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     const bool LAB_WAVE0 = wave == 0;
 #endif
     struct Frag { f32x4 q[2]; float a[2]; };
+    const int dma_pos = (wave >> 2) & 3;                             // D2T_FWD_STAGGER: where in a chunk this wave issues its DMA instructions
+    (void)dma_pos;
     auto run = [&](auto nt_c) {
         constexpr int NT = decltype(nt_c)::value;                    // tasks of this wave: 0, 1 or 2
         auto fetch = [&](Frag& f, const float* buf, int ks) {
@@ -367,9 +373,22 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
             // a DMA instruction goes behind the MFMAs of a k-step.  Behind the barrier every wave of a
             // SIMD is released at once: each first issues MFMAs it already holds the operands of.
 #define D2T_PIN() __builtin_amdgcn_sched_barrier(0)
+#if D2T_FWD_STAGGER
+            // A wave issues ALL its DMA instructions of the chunk at ONE of four points, chosen by which of its SIMD's waves it is
+            // (waves go to the SIMDs cyclically: wave >> 2).  An LDS-DMA instruction of 64 scattered pieces holds its wave ~290
+            // cycles (profiles/r05_a_ab_fwd_loader_wave.txt); with every wave issuing at the same points the four waves of a
+            // SIMD sat in them together and the matrix pipe had nobody to take an MFMA from.
+#define D2T_DMA_AT(p) if (dma_pos == (p)) { dma(s_fre, ch + 2, K0{}); dma(s_fre, ch + 2, K1{}); dma(s_fre, ch + 2, K2{}); dma(s_fre, ch + 2, K3{}); }
+            D2T_DMA_AT(0) D2T_PIN();
+            fetch(f1, cur, 1); D2T_PIN(); mfma(f0, 0, 4); D2T_DMA_AT(1) D2T_PIN();
+            fetch(f0, cur, 2); D2T_PIN(); mfma(f1, 0, 4); D2T_DMA_AT(2) D2T_PIN();
+            fetch(f1, cur, 3); D2T_PIN(); mfma(f0, 0, 4); D2T_DMA_AT(3) D2T_PIN();
+#undef D2T_DMA_AT
+#else
             fetch(f1, cur, 1); D2T_PIN(); mfma(f0, 0, 4); dma(s_fre, ch + 2, K0{}); D2T_PIN();
             fetch(f0, cur, 2); D2T_PIN(); mfma(f1, 0, 4); dma(s_fre, ch + 2, K1{}); dma(s_fre, ch + 2, K2{}); D2T_PIN();
             fetch(f1, cur, 3); D2T_PIN(); mfma(f0, 0, 4); dma(s_fre, ch + 2, K3{}); D2T_PIN();
+#endif
 #ifdef D2T_LAB
             unsigned long long tb0_, tb1_, tb2_;
             if (LAB_WAVE0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0_)::"memory");

@@ -28,6 +28,7 @@
 #include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
 #include <type_traits>
+#include "d2t_pool_common.hpp"
 #include <cstdlib>
 #include <cstring>
 
@@ -36,10 +37,8 @@ namespace d2t { namespace tuned {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int KT = 7;                         // r_hw the tuned pooling kernels are built for
-constexpr int KK = KT * KT;
+D2T_KSTAMP_DEFINE(d2t_lab_pool_bwd_stamps)
 
-inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 inline size_t bins_bytes(int R) { return align256((size_t)R * KK * 4 * sizeof(int32_t)); }
 
 // ---------------------------------------------------------------------------------------
@@ -1130,29 +1129,54 @@ static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* g
 }
 
 // ---------------------------------------------------------------------------------------
-// PSROIPool backward, ROW form (round 5): the GEMM above without its three pre-passes.  ONE launch produces the planes, the
-// gather adds them up.  Workgroup = task (cell row i, map row y), 7 waves, wave j = bin (i, j):
-//   1. all 448 threads scan the RoIs (one bin axis each: the cell row's extent, ps_roipool_cuda.cu:45-50) and compact
-//      the ones whose cell row i contains y into an LDS hit list, ascending (what k_ps_pairlists wrote to memory, with
-//      the seven column axes evaluated for EVERY RoI);
-//   2. per chunk of 32 hits: 224 threads evaluate the seven column axes of the hits and 1 / n; the others fetch the
-//      hits' gradOut runs gradOut[r][t][i][0..6] -- 28 contiguous bytes per target, so every fetched line is used for
-//      all seven bins (what k_ps_transpose_t re-laid memory for) -- into LDS as A[j][hit][target]; next chunk's loads
-//      are issued before this chunk's MFMAs;
+// PSROIPool backward, ROW form (round 5): the GEMM above without its pair-list and transposing pre-passes.  Three launches (axes,
+// rows, gather) instead of four, no (49, R, 32) copy of gradOut.  Workgroup = task (cell row i, map row y), 7 waves, wave j = bin (i, j):
+//   0. k_ps_axes (R threads) evaluates the 14 bin axes of every RoI once (ps_roipool_cuda.cu:36-54 through the same bin_axis as every
+//      other kernel): rowb[i][r], colb[r][j];
+//   1. all 448 threads scan rowb[i][.] (coalesced) and compact the RoIs whose cell row i contains y into an LDS hit list, ascending;
+//   2. per chunk of 32 hits: 224 threads fetch the hits' column bounds and 1 / n; the hits' gradOut runs gradOut[r][t][i][0..6] -- 28
+//      contiguous bytes per target, so every fetched line serves all seven bins -- go to LDS as A[j][hit][target], two lanes per run
+//      (16 bytes each); the next chunk's loads are issued before this chunk's MFMAs;
 //   3. wave j: D_j[t][x] += A_j[t][hit] * B_j[hit][x] with B = 1 / n inside the cell's columns, 0 outside
-//      (v_mfma_f32_16x16x4_f32: M = targets, N = 16 map columns, K = 4 hits; a column tile no hit reaches is skipped).
-// Every plane row is written once as an ascending-RoI chain fma(gradOut, 1 / n, acc): deterministic; <= 1 ulp per term
-// from the reference's gradOut / n (its atomics leave the order open).  Measured R = 300 nT = 21: 31 -> __ us;
-// R = 3000 nT = 4: 59 -> __ us; R = 3000 nT = 31: 72 -> __ us.
+//      (v_mfma_f32_16x16x4_f32: M = targets, N = 16 map columns, K = 4 hits; a column tile no hit of a k-step reaches is skipped).
+// Every plane row is written once as an ascending-RoI chain fma(gradOut, 1 / n, acc): deterministic; <= 1 ulp per term from the
+// reference's gradOut / n (its atomics leave the order open).
+// Measured (bench_ops.py, us; the four-launch GEMM in brackets): R = 300 nT = 21: 26 (31); R = 300 nT = 31: 34 (41); R = 3000 nT = 4: 51
+// (59); R = 3000 nT = 31: 79 (71) -- there the dispatch keeps the GEMM.  Where a task's time goes (tools/kstamps.py,
+// profiles/r05_c_kstamps_ps_rows_*.txt, R = 3000 nT = 31, 130 k cycles): the k-steps 59 k (740 cycles each: a cell is ~4 columns wide,
+// an MFMA column tile 16, and 7 waves share 4 matrix pipes), issuing the run loads 37 k (a wave pays ~20 cycles per line its
+// instruction touches, and every (hit, target) run is its own line), the hit list 11 k.  Measured and dropped: the accumulation as an
+// LDS read-add-write of the cell's own columns, lane = (target, column) -- 650 cycles per hit and wave in dependent LDS round trips,
+// 158 us (profiles/r05_c_kstamps_ps_rows_lds_rmw_lost.txt).
 // ---------------------------------------------------------------------------------------
 constexpr int PR_WAVES = KT, PR_THREADS = PR_WAVES * 64;             // 448
 constexpr int PR_EC = 32;                                            // hits per chunk = 8 k-steps
 constexpr int PR_TP = 32;                                            // targets padded to two c-tiles
 constexpr int PR_MAXHITS = 4096;                                     // LDS hit list (ints); more hits: further rounds
 
+// bin axes of every RoI, once: rowb[i][r] = i0 | i1 << 16 of cell row i (coalesced for the scan of a task), colb[r][j] = j0 | j1 << 16
+// of cell column j (32 bytes per RoI).  ps_roipool_cuda.cu:36-54 through the same bin_axis as every other kernel.
+__global__ void __launch_bounds__(256)
+k_ps_axes(const float* __restrict__ rois, int* __restrict__ rowb, int* __restrict__ colb, int R, int H, int W)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float rI = rois[4 * (size_t)r], rJ = rois[4 * (size_t)r + 1], rH = rois[4 * (size_t)r + 2], rW = rois[4 * (size_t)r + 3];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) {
+        int a0, a1, b0, b1;
+        bin_axis<float>(rI - rH / 2.0f, rH / static_cast<float>(KT), q, H, a0, a1);
+        bin_axis<float>(rJ - rW / 2.0f, rW / static_cast<float>(KT), q, W, b0, b1);
+        rowb[(size_t)q * R + r] = a0 | (a1 << 16);
+        colb[(size_t)r * 8 + q] = b0 | (b1 << 16);
+    }
+    colb[(size_t)r * 8 + 7] = 0;
+}
+
 template <int XT, int NCT>
 __global__ void __launch_bounds__(PR_THREADS)
-k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ part, int R, int nT, int H, int W)
+k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, const int* __restrict__ rowb, const int* __restrict__ colb,
+              float* __restrict__ part, int R, int nT, int H, int W)
 {
     __shared__ int hits[PR_MAXHITS];
     __shared__ int wsum[PR_WAVES + 1];
@@ -1165,6 +1189,8 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
     const int task = blockIdx.x, p = task / KT, i = task - p * KT, d = (p + 1) >> 1;
     const int y = (p & 1) ? (H - 1) / 2 + d : (H - 1) / 2 - d;
     const int j = wave;                                              // this wave's bin column
+    D2T_KSTAMP(0); D2T_KSTAMP_RT(14);
+    const int* rowi = rowb + (size_t)i * R;
     const int bin = i * KT + j;
     f32x4 acc[NCT][XT];
 #pragma unroll
@@ -1182,10 +1208,8 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
             const int r = r0 + tid;
             bool in = false;
             if (r < rend) {
-                const float rI = rois[4 * (size_t)r], rH = rois[4 * (size_t)r + 2];
-                int i0, i1;
-                bin_axis<float>(rI - rH / 2.0f, rH / static_cast<float>(KT), i, H, i0, i1);
-                in = y >= i0 && y < i1;
+                const int rb = rowi[r];
+                in = y >= (rb & 0xffff) && y < (rb >> 16);
             }
             const unsigned long long m = __ballot(in);
             const int below = __builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -1199,11 +1223,15 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
             total += cnt;
         }
         __syncthreads();
+        D2T_KSTAMP(1);
         // ---- 2 + 3. chunks of 32 hits
         const int nchunk = (total + PR_EC - 1) / PR_EC;
-        // what this thread stages per chunk: (hit e, bin column q) geometry for tid < 224; (hit, target) runs for all
-        constexpr int NRUN = (PR_EC * PR_TP + PR_THREADS - 1) / PR_THREADS;   // 3
-        float run[NRUN][KT];
+        // What a thread stages per chunk.  (hit e, bin column q) for tid < 224: column bounds and 1 / n from the axis tables.  The
+        // runs gradOut[r][t][i][0..6] -- 28 contiguous bytes -- by TWO lanes each (bytes 0..15 and 12..27, one 16-byte load per lane):
+        // a vector-memory instruction costs its wave ~15-20 cycles per line it touches, and this way 64 lanes touch 32 lines once
+        // (seven dword loads per run touched every line seven times: 20 k cycles per chunk).
+        constexpr int NLD = (2 * PR_EC * PR_TP + PR_THREADS - 1) / PR_THREADS;   // 5
+        f32x4 run[NLD];
         int gjb = 0; float gsc = 0.f;
         auto load_chunk = [&](int c) {                               // global -> registers
             const int e0 = c * PR_EC;
@@ -1211,21 +1239,19 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
                 const int e = tid / KT, q = tid - e * KT;
                 gjb = 0; gsc = 0.f;
                 if (e0 + e < total) {
-                    const float* roi = rois + 4 * (size_t)hits[e0 + e];
-                    const Bounds cb = psroi_cell<float>(roi, i, q, H, W, KT);
-                    const int nn = (cb.i1 - cb.i0) * (cb.j1 - cb.j0);
-                    gjb = cb.j0 | (cb.j1 << 16);
-                    gsc = cb.i1 > cb.i0 && cb.j1 > cb.j0 ? 1.0f / static_cast<float>(nn) : 0.f;
+                    const int r = hits[e0 + e];
+                    const int rb = rowi[r], cb = colb[(size_t)r * 8 + q];
+                    const int hh = (rb >> 16) - (rb & 0xffff), ww = (cb >> 16) - (cb & 0xffff);
+                    gjb = cb;
+                    gsc = hh > 0 && ww > 0 ? 1.0f / static_cast<float>(hh * ww) : 0.f;
                 }
             }
 #pragma unroll
-            for (int k = 0; k < NRUN; ++k) {
-                const int pr = tid + k * PR_THREADS, e = pr / PR_TP, t = pr - e * PR_TP;
-                const bool on = pr < PR_EC * PR_TP && e0 + e < total && t < nT;
-                const int off = on ? ((hits[e0 + (on ? e : 0)] * nT + t) * KK + i * KT) * 4 : 0x7ffffff0;   // out of range: zeros
-#pragma unroll
-                for (int q = 0; q < KT; ++q)
-                    run[k][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off, q * 4, 0));
+            for (int k = 0; k < NLD; ++k) {
+                const int sl = tid + k * PR_THREADS, rn = sl >> 1, half = sl & 1, e = rn / PR_TP, t = rn - e * PR_TP;
+                const bool on = rn < PR_EC * PR_TP && e0 + e < total && t < nT;
+                const int off = on ? ((hits[e0 + (on ? e : 0)] * nT + t) * KK + i * KT) * 4 + 12 * half : 0x7ffffff0;   // out of range: zeros
+                run[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
             }
         };
         auto store_chunk = [&](int buf) {                            // registers -> LDS
@@ -1234,43 +1260,64 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
                 ejb[buf][e][q] = gjb; esc[buf][e][q] = gsc;
             }
 #pragma unroll
-            for (int k = 0; k < NRUN; ++k) {
-                const int pr = tid + k * PR_THREADS, e = pr / PR_TP, t = pr - e * PR_TP;
-                if (pr < PR_EC * PR_TP) {
-#pragma unroll
-                    for (int q = 0; q < KT; ++q) A[buf][q][e][t] = run[k][q];
+            for (int k = 0; k < NLD; ++k) {
+                const int sl = tid + k * PR_THREADS, rn = sl >> 1, half = sl & 1, e = rn / PR_TP, t = rn - e * PR_TP;
+                if (rn < PR_EC * PR_TP) {
+                    if (half == 0) { A[buf][0][e][t] = run[k][0]; A[buf][1][e][t] = run[k][1]; A[buf][2][e][t] = run[k][2]; A[buf][3][e][t] = run[k][3]; }
+                    else { A[buf][4][e][t] = run[k][1]; A[buf][5][e][t] = run[k][2]; A[buf][6][e][t] = run[k][3]; }
                 }
             }
         };
         if (nchunk > 0) { load_chunk(0); store_chunk(0); }
         __syncthreads();
+        D2T_KSTAMP(2);
+        D2T_KSTAMP_ONLY(unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, tl = 0, tm = 0, ts = 0, tb = 0;)
         for (int c = 0; c < nchunk; ++c) {
             const int buf = c & 1;
+            D2T_KCLK(k0);
             if (c + 1 < nchunk) load_chunk(c + 1);                   // in flight under the MFMAs
+            D2T_KCLK(k1);
             const int ne = total - c * PR_EC < PR_EC ? total - c * PR_EC : PR_EC;
-#pragma unroll 2
-            for (int ks = 0; ks < PR_EC / 4; ++ks) {
-                if (4 * ks >= ne) break;                             // uniform
+            const int nks = (ne + 3) >> 2;                           // uniform
+            // k-steps, software-pipelined: the entry (column bounds, 1 / n, the A values of this lane's targets) of k-step ks+1 is read
+            // from LDS before the MFMAs of ks; which column tiles a k-step reaches is ONE scalar mask -- the OR of its four hits' tile
+            // ranges, read across the four lane groups -- instead of a ballot and a branch per tile
+            struct KOp { int jb; float sc; float a[NCT]; };
+            auto kfetch = [&](KOp& o, int ks) {
                 const int e = 4 * ks + g;
-                const int jb = ejb[buf][e][j];
-                const float sc = esc[buf][e][j];
-                const int j0 = jb & 0xffff, j1 = jb >> 16;
-                float a[NCT];
+                o.jb = ejb[buf][e][j];
+                o.sc = esc[buf][e][j];
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) a[ct] = A[buf][j][e][16 * ct + n];
+                for (int ct = 0; ct < NCT; ++ct) o.a[ct] = A[buf][j][e][16 * ct + n];
+            };
+            KOp cur, nxt;
+            kfetch(cur, 0);
+            for (int ks = 0; ks < nks; ++ks) {
+                if (ks + 1 < nks) kfetch(nxt, ks + 1); else nxt = cur;
+                const int j0 = cur.jb & 0xffff, j1 = cur.jb >> 16;
+                const int tb2 = cur.sc != 0.f && j1 > j0 ? ((2 << ((j1 - 1) >> 4)) - 1) & ~((1 << (j0 >> 4)) - 1) : 0;
+                const int tm2 = __builtin_amdgcn_readlane(tb2, 0) | __builtin_amdgcn_readlane(tb2, 16) | __builtin_amdgcn_readlane(tb2, 32) |
+                                __builtin_amdgcn_readlane(tb2, 48);
 #pragma unroll
                 for (int x = 0; x < XT; ++x) {
+                    if (!(tm2 & (1 << x))) continue;                 // no hit of this k-step reaches the column tile (scalar test)
                     const int col = 16 * x + n;
-                    const float b = col >= j0 && col < j1 ? sc : 0.f;
-                    if (!__builtin_amdgcn_ballot_w64(b != 0.f)) continue;   // no hit of this k-step reaches the column tile
+                    const float b = col >= j0 && col < j1 ? cur.sc : 0.f;
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], b, acc[ct][x], 0, 0, 0);
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[ct], b, acc[ct][x], 0, 0, 0);
                 }
+                cur = nxt;
             }
+            D2T_KCLK(k2);
             if (c + 1 < nchunk) store_chunk(buf ^ 1);
+            D2T_KCLK(k3);
             __syncthreads();
+            D2T_KCLK(k4);
+            D2T_KSTAMP_ONLY(tl += k1 - k0; tm += k2 - k1; ts += k3 - k2; tb += k4 - k3;)
         }
+        D2T_KSTAMP_PUT(5, tl); D2T_KSTAMP_PUT(6, tm); D2T_KSTAMP_PUT(7, ts); D2T_KSTAMP_PUT(8, tb); D2T_KSTAMP_PUT(9, (unsigned long long)nchunk);
     }
+    D2T_KSTAMP(3);
     // ---- planes: D[m = target 16 ct + 4 g + r][n = column 16 x + n]
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
@@ -1301,25 +1348,30 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
                 }
             }
         }
+    D2T_KSTAMP(4); D2T_KSTAMP_RT(15);
 }
 
 static bool psroipool_bwd_rows_supported(int R, int nT, int H, int W, int k)
 {
-    return k == KT && R >= 1 && nT >= 1 && nT <= PR_TP && H >= 1 && H <= 65535 && W >= 1 && W <= 128 &&
+    return k == KT && R >= 1 && nT >= 1 && nT <= PR_TP && H >= 1 && H <= 32767 && W >= 1 && W <= 128 &&
            1LL * R * nT * KK * 4 < 0x7ffffff0LL && 1LL * nT * KK * H * W < 0x7fffffffLL && 1LL * KT * H < 0x7fffffffLL;
 }
 
-// workspace: planes (nT*49, H*W)
+// workspace: planes (nT*49, H*W) | rowb (7, R) | colb (R, 8)
 static size_t psroipool_bwd_rows_ws_bytes(int R, int nT, int H, int W, int k)
 {
-    return psroipool_bwd_rows_supported(R, nT, H, W, k) ? align256((size_t)nT * KK * H * W * 4) : 0;
+    return psroipool_bwd_rows_supported(R, nT, H, W, k) ? align256((size_t)nT * KK * H * W * 4) + align256((size_t)KT * R * 4) + align256((size_t)R * 32) : 0;
 }
 
 static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, void* ws, hipStream_t st)
 {
-    float* part = static_cast<float*>(ws);
+    char* w = static_cast<char*>(ws);
+    float* part = reinterpret_cast<float*>(w); w += align256((size_t)nT * KK * H * W * 4);
+    int* rowb = reinterpret_cast<int*>(w); w += align256((size_t)KT * R * 4);
+    int* colb = reinterpret_cast<int*>(w);
+    hipLaunchKernelGGL(k_ps_axes, dim3((R + 255) / 256), dim3(256), 0, st, rois, rowb, colb, R, H, W);
     const int xt = (W + 15) / 16, ntasks = KT * H;
-#define D2T_LAUNCH_PR(XTV, NCTV) hipLaunchKernelGGL((k_ps_bwd_rows<XTV, NCTV>), dim3(ntasks), dim3(PR_THREADS), 0, st, gout, rois, part, R, nT, H, W)
+#define D2T_LAUNCH_PR(XTV, NCTV) hipLaunchKernelGGL((k_ps_bwd_rows<XTV, NCTV>), dim3(ntasks), dim3(PR_THREADS), 0, st, gout, rois, rowb, colb, part, R, nT, H, W)
 #define D2T_LAUNCH_PR_X(NCTV) { if (xt <= 4) D2T_LAUNCH_PR(4, NCTV); else if (xt <= 5) D2T_LAUNCH_PR(5, NCTV); else D2T_LAUNCH_PR(8, NCTV); }
     if (nT <= 16) D2T_LAUNCH_PR_X(1) else D2T_LAUNCH_PR_X(2)
 #undef D2T_LAUNCH_PR_X
@@ -1365,7 +1417,7 @@ static int ps_bwd_design(int R, int nT, int H, int W, int k)
     // measured grid R in {300..3000} x nT in {4..31} on a 38x75 map (tools/ps_scan.py, profiles/r02_b_ps_bwd_scan_*):
     // the GEMM wins from 12 targets up at every R (R=300 nT=16: 33 vs 40 us; R=3000 nT=31: 73 vs 148 sorted / 278 planes)
     // and from 8 targets at R >= 1000; the plane kernels keep the small shapes (R=300 nT=4: 15 vs 25 us)
-    if (rw && f == 0) return 3;                                       // round 5: the row form takes every shape it supports
+    if (rw && f == 0 && !(g && nT >= 12 && R >= 1500)) return 3;       // round 5: the row form -- except many targets x thousands of RoIs (R = 3000 nT = 31: 79 against 71 us)
     if (g && (nT >= 12 || (nT >= 8 && R >= 1000) || !p)) return 2;
     if (s && (!p || (nT >= PS_SORTED_MIN_TARGETS && 1LL * R * nT >= PS_SORTED_MIN_WORK))) return 1;
     return p ? 0 : (s ? 1 : 0);

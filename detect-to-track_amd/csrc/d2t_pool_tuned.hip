@@ -198,6 +198,13 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const float* __restrict__ rois, 
 // owns a bin and produces both channels: a corner is ONE ds_read_b128 for two outputs instead of two
 // ds_read_b64 -- half the LDS instructions of the look-up phase, and 16-byte accesses at RoI-dependent
 // addresses conflict less than 8-byte ones (the planar kernel's SQ_LDS_BANK_CONFLICT is 52 % of its LDS time).
+// Round 5, what the workgroup's clocks say (tools/kstamps.py, profiles/r05_c_kstamps_roipool_fwd_*.txt; config 3, cycles per workgroup):
+// planes into LDS 8.6 k, prefix2d 8.0 k, geometry of 240 RoIs 4.1 k, look-ups 8.1 k, geometry of the last 60 5.4 k, look-ups 3.0 k =
+// 37.7 k = 16 us -- and only 256 of the 512 workgroups are resident at a time (one per CU although two fit by LDS, waves and registers:
+// the 100 MHz clock at entry / exit shows two rounds), so the op is two rounds of latency-bound phases, not its 54 % LDS bank
+// conflicts.  Measured and dropped: the geometry of all RoIs evaluated under the plane loads' latency (workgroup 37.7 k -> 29.7 k
+// cycles, but the op 31.4 -> 34.2 us: the second round starts later); the 2-D prefix as wave-wide f64 row scans (12.7 k cycles against
+// 8.0 k); not raising the dynamic-LDS limit (still one workgroup per CU).
 // ---------------------------------------------------------------------------------------
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int S2_THREADS = 1024;             // two workgroups per CU (45 KB of LDS each); 512 threads x 4 per CU measured 35.5 us against 32.8

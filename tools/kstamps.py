@@ -18,7 +18,7 @@ lib, dev = _native.lib, "cuda:0"
 NWG = 16384
 
 
-def run(setter, call, names):
+def run(setter, call, names, extra=None):
     fn = getattr(lib, setter)
     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
     stamps = torch.zeros(NWG, 16, dtype=torch.int64, device=dev)
@@ -31,14 +31,22 @@ def run(setter, call, names):
     assert fn(None) == 0
     s = stamps.cpu().numpy()
     s = s[s[:, 0] != 0]
-    print(f"{len(s)} workgroups stamped; first entry -> last stamp {(s.max() - s[:, 0].min())} cycles")
+    print(f"{len(s)} workgroups stamped")
     for i in range(1, len(names)):
         on = (s[:, i] != 0) & (s[:, i - 1] != 0)
         if on.any():
             d = s[on, i] - s[on, i - 1]
             print(f"   {names[i - 1]:28s} -> {names[i]:28s}: median {np.median(d):8.0f}  max {d.max():8d}  ({on.sum()} WGs)")
+    if s[:, 14].any() and s[:, 15].any():                            # 100 MHz wall clock at entry / exit: how many workgroups run at a time
+        t0, t1 = s[:, 14], s[:, 15]
+        mid = np.linspace(t0.min(), t1.max(), 41)[1:-1]
+        conc = [int(((t0 <= m) & (t1 >= m)).sum()) for m in mid]
+        print(f"   wall clock: kernel span {(t1.max() - t0.min()) / 100:.1f} us, workgroup lifetime median {np.median(t1 - t0) / 100:.1f} us, "
+              f"entry skew {(t0.max() - t0.min()) / 100:.1f} us, resident workgroups over time (39 samples): min {min(conc)} median {int(np.median(conc))} max {max(conc)}")
+    for slot, name in (extra or {}).items():
+        print(f"   wave 0, summed over the chunks: {name:36s} median {np.median(s[:, slot]):9.0f}  max {s[:, slot].max():9d}")
     last = np.max(s[:, 1:len(names)], axis=1)
-    print(f"   workgroup lifetime: median {np.median(last - s[:, 0]):.0f} max {(last - s[:, 0]).max()} cycles; entry skew {s[:, 0].max() - s[:, 0].min()}")
+    print(f"   workgroup lifetime: median {np.median(last - s[:, 0]):.0f} max {(last - s[:, 0]).max()} cycles")
 
 
 def main():
@@ -51,6 +59,18 @@ def main():
         run("d2t_lab_pool_fwd_stamps",
             lambda: bench_ops._check(lib.d2t_roipool_fwd_f32(fm.data_ptr(), rois.data_ptr(), out.data_ptr(), R, C, H, W, K, 0, 0, 0, st)),
             ["entry", "planes in LDS", "prefix2d done", "geometry 1 done", "look-ups 1 done", "geometry 2 done", "look-ups 2 done", "end"])
+    if what.startswith("psroipool_bwd"):
+        R, nT = (int(x) for x in (sys.argv[2], sys.argv[3])) if len(sys.argv) > 3 else (3000, 31)
+        H, W, K = 38, 75, 7
+        go, gin = torch.rand(R, nT, K, K, device=dev), torch.empty(nT * K * K, H, W, device=dev)
+        rois = torch.from_numpy(bench_ops.random_rois(R, 1)).to(dev)
+        nb = lib.d2t_psroipool_bwd_workspace_bytes(R, nT, H, W, K, 4)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        print(f"psroipool backward R={R} nT={nT} {H}x{W}")
+        run("d2t_lab_pool_bwd_stamps",
+            lambda: bench_ops._check(lib.d2t_psroipool_bwd_f32(go.data_ptr(), rois.data_ptr(), gin.data_ptr(), R, nT, H, W, K, ws.data_ptr(), nb, 0, st)),
+            ["entry", "hit list done", "chunk 0 staged", "chunks done", "end"],
+            extra={5: "load_chunk issue", 6: "k-steps (LDS reads + MFMA)", 7: "store_chunk (waits for the loads)", 8: "barrier", 9: "chunks"})
 
 
 if __name__ == "__main__":
