@@ -35,7 +35,7 @@ try:
     TRAFFIC = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get("ops", {})
 except Exception:
     TRAFFIC = {}
-MARKER = None          # tools/ops_pmc.sh: called with (label, calls) in front of every timed series
+MARKER = None          # tools/ops_pmc.sh: called with (label, calls) in front of every timed series and with (None, 1) behind it
 
 
 def label_of(op, shape, direction):
@@ -68,6 +68,8 @@ def timed(fn, iters, nsets, label=None):
         fn(i % nsets)
     b.record()
     torch.cuda.synchronize()
+    if MARKER is not None:
+        MARKER(None, 1)                              # closes the series: what follows (the next shape's inputs) belongs to no label
     return a.elapsed_time(b) / iters * 1e3           # us
 
 

@@ -126,10 +126,15 @@ inline const char* lab_env_str(const char*) { return nullptr; }
 #ifdef D2T_ENV_KNOBS
 #define D2T_KSTAMP_DEFINE(setter)                                                                     \
     static __device__ unsigned long long* kstamps_;                                                   \
+    static __device__ int kdbg_;                          /* ablation bits of a knob build (D2T_KDBG) */ \
     extern "C" int setter(void* p)                                                                    \
     {                                                                                                 \
         unsigned long long* q = static_cast<unsigned long long*>(p);                                  \
         return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(kstamps_), &q, sizeof(q)));              \
+    }                                                                                                 \
+    extern "C" int setter##_dbg(int bits)                                                             \
+    {                                                                                                 \
+        return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(kdbg_), &bits, sizeof(bits)));           \
     }
 #define D2T_KSTAMP(i)                                                                                 \
     do {                                                                                              \
@@ -150,6 +155,7 @@ inline const char* lab_env_str(const char*) { return nullptr; }
 #define D2T_KCLK(var) do { if (kstamps_) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); } while (0)
 #define D2T_KSTAMP_PUT(i, val) do { if (kstamps_ && threadIdx.x == 0) kstamps_[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = (val); } while (0)
 #define D2T_KSTAMP_ONLY(...) __VA_ARGS__
+#define D2T_KDBG (kdbg_)
 #else
 #define D2T_KSTAMP_DEFINE(setter)
 #define D2T_KSTAMP(i)
@@ -157,6 +163,7 @@ inline const char* lab_env_str(const char*) { return nullptr; }
 #define D2T_KCLK(var)
 #define D2T_KSTAMP_PUT(i, val)
 #define D2T_KSTAMP_ONLY(...)
+#define D2T_KDBG 0
 #endif
 
 inline bool fits_i32(long long v) { return v >= 0 && v <= 2147483647LL; }

@@ -36,6 +36,8 @@ namespace d2t { namespace tuned {
 // in-kernel stamps of the stamp build (-DD2T_ENV_KNOBS -DD2T_BAND_STAMPS) (tools/band_scan.py --stamps): [workgroup][16] clock reads of compute wave 0 (0-4) and of the first
 // loader wave (8-13), s_memrealtime at entry / exit (14, 15).  The product library is built without D2T_ENV_KNOBS: no stamp executes there.
 __device__ unsigned long long* band_stamps;
+__device__ int band_dbg;                          // ablation bits: 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads, 8 no stores
+#define BAND_DBG (band_dbg)
 #define BAND_STAMP(cond, i)                                                                           \
     do {                                                                                              \
         if (band_stamps && (cond) && (threadIdx.x & 63) == 0) {                                       \
@@ -57,6 +59,7 @@ __device__ unsigned long long* band_stamps;
 #define BAND_STAMP(cond, i)
 #define BAND_STAMP_RT(cond, i)
 #define BAND_CLK(var)
+#define BAND_DBG 0
 #endif
 
 namespace {
@@ -181,7 +184,9 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
             }
         }
         const int chunk_bytes = KC * HW * 4;
+        const int dbg = BAND_DBG;
         auto stage = [&](int slot, int chunk) {                      // chunks past the end of C arrive as zeros
+            if (dbg & 1) return;
             const int cb = chunk * chunk_bytes;
             // chunks nobody multiplies (behind chunk nchunks, which is fetched but unused) are parked whole: the ring is quiet when the
             // last barrier has been passed, and the epilogue may use its memory
@@ -224,7 +229,9 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the parked instructions staged past the end
     } else {
         struct Frag { frag_t q[KC / 4]; float a[KC / 4]; };
+        const int dbg = BAND_DBG;
         auto fetch = [&](Frag& f, const float* cur) {
+            if (dbg & 4) return;
 #pragma unroll
             for (int ks = 0; ks < KC / 4; ++ks) {
                 f.q[ks] = *reinterpret_cast<const frag_t*>(cur + l_off + ks * 4 * S::BPL);
@@ -232,7 +239,7 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
             }
         };
         auto mfma = [&](const Frag& f, int ks_lo, int ks_hi) {
-            if (!t_on) return;                                       // wave-uniform
+            if (!t_on || (dbg & 2)) return;                          // wave-uniform
 #pragma unroll
             for (int ks = ks_lo; ks < ks_hi; ++ks)
 #pragma unroll
@@ -262,6 +269,7 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     // zeros (cj = 16, ci = 16, displaced columns outside the map) included -- and the task's waves store the runs with consecutive
     // lanes on consecutive cells.  (Straight from the registers, as at first: 12-16 exec-masked store instructions per wave, each
     // touching a dozen lines -- and 4 KB of straight-line code that every wave of the chip fetched cold at the same moment.)
+    if (BAND_DBG & 8) return;                                        // (stamp builds: no stores; kernel-wide, nothing below is skipped by a part of a workgroup)
     const int gf = 16 * T, gl = (gf + 15 < ng ? gf + 15 : ng - 1);   // the task's first / last group (wave-uniform)
     if (HT == 1 && lay.cs == 1) {
         // Reference layout, one wave per task: straight from the accumulators.  The four s of a lane are adjacent cells, so a lane
@@ -416,7 +424,13 @@ int corr_fwd_band_config(int B, int H, int W)
     if (forced >= 0) return forced;
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     const long long tasks = 6LL * B * tiles_i * tiles_j;
-    if (tasks > 2600) return 0;                                      // larger grids: the segment kernels of d2t_corr_tuned.hip
+    if (tasks > 2600) {
+        // Medium grids (B = 3 .. 5 at the model's maps: too few 5-tile segments for k_corr_fwd_seg, several rounds of band workgroups).
+        // tools/band_scan.py, us, two-tile segments -> band: B 4 C 256 38 x 63 51 -> 33 (TW 4 x NB 2: 480 workgroups of 8 + 4 waves, two
+        // per CU), B 3 C 1024 38 x 75 161 -> 98 (NB 2), B 5 C 256 38 x 63 52 -> 44 and B 5 C 1024 38 x 75 171 -> 151 (NB 1; NB 2 loses there).
+        const long long n42 = 3LL * B * tiles_i * ((tiles_j + 3) / 4);
+        return n42 > 400 && n42 <= 512 ? 142 : 141;
+    }
     // One workgroup per CU is what pays (profiles/r05_b_band_scan.txt, us): 38 x 63 -- 16 tile columns, TW 4: 240 workgroups -- B = 1 C = 256
     // 11.8 (one-tile kernel 17.7); 38 x 75 -- 19 tile columns -- TW 4: 300 workgroups, 44 CUs carry two: C = 2048 83.6; TW 5 with two waves
     // per task (10 computing + 6 loader waves): 240 workgroups, 69.0 (one-tile kernel 115).  Grids of several rounds (B = 2): TW 4.
@@ -430,14 +444,17 @@ int corr_fwd_band_f32(int cfg, const float* fm0, const float* fm1, float* out, i
 #define D2T_BAND_CASE(id, TW, NB, HT, KC, RING, WL) case id: return launch_band<TW, NB, HT, KC, RING, WL>(fm0, fm1, out, B, C, H, W, lay, st);
         D2T_BAND_CASE(141, 4, 1, 1, 16, 3, 4)
         D2T_BAND_CASE(1251, 5, 1, 2, 16, 3, 6)
+        D2T_BAND_CASE(142, 4, 2, 1, 16, 3, 4)
 #ifdef D2T_ENV_KNOBS                                                  /* scan builds (tools/band_scan.py) */
         D2T_BAND_CASE(1141, 4, 1, 1, 16, 3, 8)
         D2T_BAND_CASE(151, 5, 1, 1, 16, 3, 4)
         D2T_BAND_CASE(251, 5, 1, 2, 16, 3, 4)
         D2T_BAND_CASE(241, 4, 1, 2, 16, 3, 4)
         D2T_BAND_CASE(131, 3, 1, 1, 16, 3, 4)
-        D2T_BAND_CASE(142, 4, 2, 1, 16, 3, 4)
         D2T_BAND_CASE(123, 2, 3, 1, 16, 3, 4)
+        D2T_BAND_CASE(143, 4, 3, 1, 16, 3, 4)
+        D2T_BAND_CASE(126, 2, 6, 1, 16, 3, 4)
+        D2T_BAND_CASE(133, 3, 3, 1, 16, 3, 4)
 #endif
 #undef D2T_BAND_CASE
         default: return D2T_EINVAL;
@@ -450,6 +467,7 @@ extern "C" int d2t_lab_band_stamps(void* p)                          // scan bui
     unsigned long long* q = static_cast<unsigned long long*>(p);
     return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(band_stamps), &q, sizeof(q)));
 }
+extern "C" int d2t_lab_band_dbg(int bits) { return static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(band_dbg), &bits, sizeof(bits))); }
 #endif
 
 }}  // namespace d2t::tuned

@@ -642,256 +642,9 @@ k_corr_fwd_combine(CombineLevels lv, int B, int HW, CellLayout lay)
     }
 }
 
-// ------------------------------------------------------------------------------------
-// Forward, small grids (the real model's B = 1 pairs: 160-190 p-tiles in all).  Same LDS-staged
-// scheme as k_corr_fwd_seg with short segments (NU = 1 or 2 p-tiles, 3*NU waves) so that every CU
-// gets a workgroup.  With so few waves per CU nothing hides the DMA latency of a chunk behind the
-// MFMAs of a single other chunk, so the chunks go through a RING of staged buffers: chunk ch is
-// consumed while ch+1 .. ch+RING-1 are in flight.  LDS-DMA loads retire in order and every wave
-// issues exactly NDMA of them per chunk (surplus ones are parked out of range and land as zeros in
-// a dummy slot), so "vmcnt <= (RING-2)*NDMA" means this wave's part of chunk ch+1 has landed; the
-// barrier then publishes all parts.  (__syncthreads() would wait for vmcnt(0) and serialise the
-// latency.)  Arithmetic unchanged: bit-identical to the other forward kernels.
-// ------------------------------------------------------------------------------------
-template <int NU, int RING, bool SPLIT = false>
-struct SegX {
-    // 6*NU (tile, tile-group) tasks, two per wave -- or, SPLIT (one tile): FOUR waves with a tile-group and
-    // a HALF tile-group (2 of its 4 N-tiles) each, so that all four SIMDs of the CU carry 6 N-tiles
-    // instead of three carrying 8 (the B = 1 kernel is bound by its longest MFMA chain)
-    static constexpr int WAVES = SPLIT ? 4 : 3 * NU;
-    static_assert(!SPLIT || NU == 1, "SPLIT is the one-tile layout");
-    static constexpr int THREADS = WAVES * 64;
-    static constexpr int ROWS = 4 * NU + 2 * DT - 1;                 // window rows of a segment
-    static constexpr int SLOTS = (ROWS * NCG + 15) / 16 * 16;        // 16-byte slots per channel: plane stride = 0 mod 64 dwords
-    static constexpr int BPL = SLOTS * 4;
-    static constexpr int APL = NU * 16;
-    static constexpr int BUF = SG_KC * (BPL + APL);                  // floats per staged chunk
-    static constexpr int STAGE = NU * 16 * CELLS;                    // out staging, aliases the ring
-    static constexpr int DUMMY = 256;                                // floats: where parked DMA instructions land
-    static constexpr int LDS = RING * BUF + DUMMY > STAGE ? RING * BUF + DUMMY : STAGE;
-    static constexpr int BI = SG_KC * SLOTS / 64;                    // FM1 DMA wave-instructions per chunk
-    static constexpr int AI = SG_KC * 4 * NU / 64;                   // FM0 ones
-    static constexpr int KB = (BI + WAVES - 1) / WAVES;              // FM1 / FM0 DMA instructions per wave per chunk:
-    static constexpr int KA = (AI + WAVES - 1) / WAVES;              // the same count (and kind, per position) for every wave
-    static constexpr int NDMA = KB + KA;
-    static constexpr int INFLIGHT = (RING - 3) * NDMA;               // DMA instructions that may still be outstanding at a barrier
-    static_assert(INFLIGHT <= 63, "vmcnt is a 6-bit counter");
-    static_assert(LDS * 4 <= 160 * 1024, "LDS budget");
-};
-
-template <int NU, int RING, bool SPLIT = false>
-__global__ void __launch_bounds__((SPLIT ? 4 : 3 * NU) * 64)
-k_corr_fwd_segx(FwdLevels lv, int H, int W, int tiles_i, int tiles_j, int nseg, CellLayout lay)
-{
-    using S = SegX<NU, RING, SPLIT>;
-    __shared__ __attribute__((aligned(16))) float smem[S::LDS];
-
-    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // level of this workgroup (wave-uniform scalar selects: the arrays live in kernel-argument SGPRs)
-    const int gl = xcd_remap(blockIdx.x, gridDim.x);                 // global logical id (see k_corr_fwd_seg_split)
-    int L = 0, wg0 = 0;
-#pragma unroll
-    for (int l = 1; l < MAXLV; ++l)
-        if (l < lv.n && gl >= lv.wg_end[l - 1]) { L = l; wg0 = lv.wg_end[l - 1]; }
-    const float* __restrict__ fm0 = lv.fm0[0];
-    const float* __restrict__ fm1 = lv.fm1[0];
-    float* __restrict__ out = lv.out[0];
-    int C = lv.C[0];
-#pragma unroll
-    for (int l = 1; l < MAXLV; ++l)
-        if (L == l) { fm0 = lv.fm0[l]; fm1 = lv.fm1[l]; out = lv.out[l]; C = lv.C[l]; }
-    const int bid = gl - wg0;
-    const int seg = bid % nseg, tj = (bid / nseg) % tiles_j, b = bid / (nseg * tiles_j);
-    const int u0 = seg * NU, nu = tiles_i - u0 < NU ? tiles_i - u0 : NU;
-    const int j0 = tj * TP, HW = H * W;
-    const unsigned plane_bytes = (unsigned)C * HW * 4u;
-    const __amdgpu_buffer_rsrc_t r1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm1 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fm0 + (size_t)b * C * HW), 0, plane_bytes, 0x00020000);
-    float* outb = out + (size_t)b * lay.bs;
-    const __amdgpu_buffer_rsrc_t ro =
-        __builtin_amdgcn_make_buffer_rsrc(outb, 0, (unsigned)HW * CELLS * 4u, 0x00020000);
-
-    const int R0 = 4 * u0 - DT > 0 ? 4 * u0 - DT : 0;                // region rows [R0, R1) inside the map
-    const int R1 = 4 * (u0 + nu) + DT - 1 < H ? 4 * (u0 + nu) + DT - 1 : H;
-    const int nrows = R1 - R0;
-    const int colL = j0 - DT;                                        // region columns [colL, colL+20): may leave the map
-
-    // ---- DMA plan: a wave-instruction moves 64 pieces of 16 bytes.  Position k < KB of a wave's
-    // sequence is FM1 instruction x = wave + WAVES*k (slots 64x .. 64x+63 of the [channel][row]
-    // [column group] image), position KB + k is FM0 instruction x = wave + WAVES*k (pieces (channel,
-    // pixel row of the segment)); an x past the end is parked: out of range -> zeros into the dummy
-    // slot.  The kind of every position is static, so staging is branch-free.
-    constexpr int OOR = 0x7ffffff0;
-    int dv[S::NDMA], dl[S::NDMA];                                    // byte offset in the planes / float offset in the buffer
-#pragma unroll
-    for (int k = 0; k < S::KB; ++k) {
-        const int x = wave + S::WAVES * k;
-        const int e = x * 64 + lane;
-        const int ch = e / S::SLOTS, rem = e - ch * S::SLOTS;
-        const int row = rem / NCG, cg = rem - row * NCG;             // pad slots have row >= ROWS >= nrows
-        dv[k] = x < S::BI && row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 : OOR;
-        dl[k] = x < S::BI ? x * 256 : -1;
-    }
-#pragma unroll
-    for (int k = 0; k < S::KA; ++k) {
-        const int x = wave + S::WAVES * k;
-        const int e = x * 64 + lane;
-        const int ch = e / (4 * NU), prow = e - ch * (4 * NU);
-        const int i = 4 * u0 + prow;
-        dv[S::KB + k] = x < S::AI && i < H ? (ch * HW + i * W + j0) * 4 : OOR;
-        dl[S::KB + k] = x < S::AI ? SG_KC * S::BPL + x * 256 : -1;
-    }
-    const int chunk_bytes = SG_KC * HW * 4;
-    auto stage = [&](float* buf, int chunk) {
-        const int cb = chunk * chunk_bytes;
-#pragma unroll
-        for (int k = 0; k < S::NDMA; ++k) {
-            const int v = dv[k] == OOR ? OOR : dv[k] + cb;
-            float* dst = dl[k] >= 0 ? buf + dl[k] : smem + RING * S::BUF;
-            if (k < S::KB) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, v, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)dst, 16, v, 0, 0, 0);
-        }
-    };
-
-    // ---- this wave's two tasks: id = tile*6 + tile-group.  SPLIT: task 0 is a whole tile-group (0, 2, 3, 5
-    // for waves 0..3), task 1 one half of tile-group 1 (waves 0, 1) or 4 (waves 2, 3): N-tiles
-    // {0,1} for the even wave, {2,3} for the odd one.
-    const int hsel = SPLIT ? (wave & 1) : 0;                         // which half of task 1's quad (wave-uniform)
-    auto task_id = [&](int k) { return SPLIT ? (k == 0 ? (wave < 2 ? 2 * wave : 2 * wave - 1) : (wave < 2 ? 1 : 4)) : wave + S::WAVES * k; };
-    int t_tile[2], t_off[2], t_ng[2];
-    bool t_on[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int id = task_id(k), t = id / 6, T = id - t * 6;
-        const int u = u0 + t;
-        const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;              // tile's window rows inside the map
-        const int wb = 4 * u + TP + DT - 1 < H ? 4 * u + TP + DT - 1 : H;
-        const int ng = (wb - wa) * NCG;
-        t_tile[k] = t;
-        t_ng[k] = ng;
-        t_on[k] = t < nu && 16 * T < ng;
-        t_off[k] = ((wa - R0) * NCG + 16 * T) * 4;                   // float offset of the tile-group's first slot
-    }
-    int l_off[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int T = task_id(k) % 6;
-        int gi = 16 * T + n;
-        gi = gi < t_ng[k] ? gi : (t_ng[k] > 0 ? t_ng[k] - 1 : 0);
-        l_off[k] = t_on[k] ? t_off[k] - 16 * T * 4 + gi * 4 + g * S::BPL : g * S::BPL;
-    }
-    if (SPLIT) l_off[1] += 2 * hsel;                                 // the half quad this wave multiplies
-    const int a_off0 = SG_KC * S::BPL + g * S::APL + (t_on[0] ? t_tile[0] : 0) * 16 + n;
-    const int a_off1 = SG_KC * S::BPL + g * S::APL + (t_on[1] ? t_tile[1] : 0) * 16 + n;
-
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[k][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = (C + SG_KC - 1) / SG_KC;
-    // MFMA fragments of a chunk (both tasks; a missing task reads a valid slot into a dead
-    // accumulator, so the loop body is straight-line)
-    struct Frag { f32x4 q0[SG_KC / 4], q1[SG_KC / 4]; float a0[SG_KC / 4], a1[SG_KC / 4]; };
-    auto fetch = [&](Frag& f, const float* cur) {
-#pragma unroll
-        for (int ks = 0; ks < SG_KC / 4; ++ks) {
-            f.q0[ks] = *reinterpret_cast<const f32x4*>(cur + l_off[0] + ks * 4 * S::BPL);
-            if constexpr (SPLIT) {
-                const f32x2 h = *reinterpret_cast<const f32x2*>(cur + l_off[1] + ks * 4 * S::BPL);
-                f.q1[ks] = f32x4{h.x, h.y, 0.f, 0.f};
-            } else {
-                f.q1[ks] = *reinterpret_cast<const f32x4*>(cur + l_off[1] + ks * 4 * S::BPL);
-            }
-            f.a0[ks] = cur[a_off0 + ks * 4 * S::APL];
-            f.a1[ks] = cur[a_off1 + ks * 4 * S::APL];
-        }
-    };
-#pragma unroll
-    for (int p = 0; p < RING - 1; ++p) stage(smem + p * S::BUF, p);  // past the end of C: zeros
-    dma_wait_barrier<S::INFLIGHT>();                                 // chunks 0 and 1 have landed
-    Frag cur_f, nxt_f;
-    fetch(cur_f, smem);
-    int slot = 0;                                                    // ring slot of chunk ch
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int free_slot = slot == 0 ? RING - 1 : slot - 1;       // chunk ch-1: in registers since iteration ch-2
-        const int next_slot = slot + 1 == RING ? 0 : slot + 1;       // chunk ch+1: published by the last barrier
-        stage(smem + free_slot * S::BUF, ch + RING - 1);
-        fetch(nxt_f, smem + next_slot * S::BUF);                     // lands under this chunk's MFMAs
-#pragma unroll
-        for (int ks = 0; ks < SG_KC / 4; ++ks) {
-            acc[0][0] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].x, acc[0][0]);
-            acc[1][0] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].x, acc[1][0]);
-            acc[0][1] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].y, acc[0][1]);
-            acc[1][1] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].y, acc[1][1]);
-            acc[0][2] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].z, acc[0][2]);
-            if (!SPLIT) acc[1][2] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].z, acc[1][2]);
-            acc[0][3] = D2T_MFMA(cur_f.a0[ks], cur_f.q0[ks].w, acc[0][3]);
-            if (!SPLIT) acc[1][3] = D2T_MFMA(cur_f.a1[ks], cur_f.q1[ks].w, acc[1][3]);
-        }
-        dma_wait_barrier<S::INFLIGHT>();                             // chunk ch+2 has landed; chunk ch+1 is in registers
-        cur_f = nxt_f;
-        slot = next_slot;
-    }
-    __syncthreads();                                                 // vmcnt(0): the zero chunks staged past the end
-
-    // ---- epilogue: [nu tiles][16 pixels][17][17] through LDS, then 4*nu contiguous runs ----
-    for (int e = tid; e < nu * 16 * CELLS; e += S::THREADS) smem[e] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int T = task_id(k) % 6;
-        const int gi = 16 * T + n;
-        if (t_on[k] && gi < t_ng[k]) {
-            const int u = u0 + t_tile[k];
-            const int wa = 4 * u - DT > 0 ? 4 * u - DT : 0;
-            const int rho = wa + gi / NCG, cg = gi - (gi / NCG) * NCG;   // displaced row, column group
-            const int ci = rho - (4 * u + g) + DT;                   // di - i + d, pixel row i = 4u + g
-            if (ci >= 0 && ci < 2 * DT) {
-                float* row = smem + (t_tile[k] * 16 + 4 * g) * CELLS + ci * CW;
-#pragma unroll
-                for (int s = 0; s < (SPLIT && k == 1 ? 2 : 4); ++s) {
-                    const int dj = colL + 4 * cg + s + (SPLIT && k == 1 ? 2 * hsel : 0);   // SPLIT task 1: N-tiles 2*hsel + s
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int cj = dj - (j0 + r) + DT;
-                        if (cj >= 0 && cj < 2 * DT && dj >= 0 && dj < W) row[r * CELLS + cj] = acc[k][s][r];
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int nj = W - j0 < TP ? W - j0 : TP;
-    const int run = nj * CELLS, run4 = run >> 2;                     // floats / whole float4s per pixel row
-    const int prs = (H - 4 * u0 < 4 * nu ? H - 4 * u0 : 4 * nu);     // pixel rows that exist
-    if (lay.cs != 1) {
-        // channel-major: cell c of pixel row pr is the 16-byte piece out[c][4*u0+pr][j0..j0+3]; consecutive
-        // threads take consecutive cells (consecutive LDS words, pieces H*W*4 bytes apart in memory)
-        for (int e = tid; e < prs * CELLS; e += S::THREADS) {
-            const int pr = e / CELLS, c = e - pr * CELLS;
-            const float* src = smem + (size_t)pr * 4 * CELLS + c;
-            float* dst = outb + (size_t)c * lay.cs + ((size_t)(4 * u0 + pr) * W + j0) * lay.ps;
-            for (int r = 0; r < nj; ++r) dst[(size_t)r * lay.ps] = src[r * CELLS];
-        }
-        return;
-    }
-    for (int e = tid; e < prs * run4; e += S::THREADS) {
-        const int pr = e / run4, q = e - pr * run4;
-        const int off = (((4 * u0 + pr) * W + j0) * CELLS + 4 * q) * 4;
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + (size_t)pr * 4 * CELLS + 4 * q),
-                                               ro, off, 0, 16);     // aux 16 = sc1 (write-through)
-    }
-    const int tail = run - 4 * run4;                                 // 0..3 floats per pixel row (nj < 4)
-    for (int e = tid; e < prs * tail; e += S::THREADS) {
-        const int pr = e / tail, q = 4 * run4 + (e - pr * tail);
-        outb[((size_t)(4 * u0 + pr) * W + j0) * CELLS + q] = smem[(size_t)pr * 4 * CELLS + q];
-    }
-}
+#ifdef D2T_ENV_KNOBS
+#include "lab/d2t_corr_fwd_segx.inc"       // scan builds only: the one- / two-tile forward the band-split kernel replaced
+#endif
 
 bool corr_fwd_supported(int B, int C, int H, int W, int d, int s)
 {
@@ -955,6 +708,15 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP;
     const int nseg = (tiles_i + SG_NU - 1) / SG_NU;
     const long long strip_blocks = 1LL * B * tiles_j * nseg;
+#ifdef D2T_ENV_KNOBS
+    if (lab_env_int("D2T_BAND_CFG", -1) > 0) {       // scan builds: the band-split kernel on any grid (tools/band_scan.py)
+        for (int l = 0; l < nl; ++l) {
+            const int rc = corr_fwd_band_f32(lab_env_int("D2T_BAND_CFG", -1), fm0[l], fm1[l], out[l], B, C[l], H, W, lay, st);
+            if (rc != D2T_OK) return rc;
+        }
+        return D2T_OK;
+    }
+#endif
     if (strip_blocks >= 192) {                       // enough segments to give (nearly) every CU one
         for (int l = 0; l < nl; ++l)
             hipLaunchKernelGGL(k_corr_fwd_seg, dim3((int)strip_blocks), dim3(SG_THREADS), 0, st,
@@ -995,6 +757,9 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
         }
         return D2T_OK;
     }
+#ifndef D2T_ENV_KNOBS
+    return D2T_EINVAL;                               // not reached: corr_fwd_band_config names a shape for every grid of the envelope
+#else                                                // scan builds, D2T_BAND_CFG=0: the one- / two-tile kernels of rounds 1-4
     int order[MAXLV];
     for (int l = 0; l < nl; ++l) order[l] = l;
     for (int a = 0; a < nl; ++a)                     // heaviest first (nl <= 4)
@@ -1027,6 +792,7 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
                                lv, H, W, tiles_i, tiles_j, ns, lay);
     }
     return launch_status();
+#endif
 }
 
 int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, int, int,

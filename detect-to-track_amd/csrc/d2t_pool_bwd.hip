@@ -399,6 +399,8 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
     // task to whichever CU frees a slot -- a work queue without the ~3 us per task an atomic counter +
     // broadcast cost when tried.  Tasks are numbered from the MIDDLE rows outwards (mid, mid+1, mid-1, ...):
     // RoIs crowd the middle of the map, and the long tasks should start first.
+    D2T_KSTAMP(0); D2T_KSTAMP_RT(14);
+    const int dbg = D2T_KDBG;                                        // knob builds: 1 = no gradOut loads, 2 = no MFMA, 4 = no list reads in the k-steps
     for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
         const int p = t / ncb, d = (p + 1) >> 1, y = (p & 1) ? (H - 1) / 2 + d : (H - 1) / 2 - d;
         const int c0 = (t - p * ncb) * (16 * NCT);
@@ -426,6 +428,7 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
             const int mine = (kp - wave + NW - 1) / NW;
             f32x2 av[RG_PF][NCT];
             auto a_load = [&](int m, int ct) -> f32x2 {
+                if (dbg & 1) return f32x2{1.f, 1.f};
                 const int go = list[8 * (wave + NW * m) + g].goff;
                 return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, (int)((unsigned)(gach[ct] + go) * 4u), 0, 0));
             };
@@ -446,7 +449,7 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
                     for (int ct = 0; ct < NCT; ++ct) av[q][ct] = nxt < mine ? a_load(nxt, ct) : f32x2{0.f, 0.f};
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {                    // the pair's two k-steps
-                        const RmSlot e = list[8 * (wave + NW * (m < mine ? m : 0)) + 4 * h + g];
+                        const RmSlot e = list[(dbg & 4) ? g : 8 * (wave + NW * (m < mine ? m : 0)) + 4 * h + g];
                         const float sc = m < mine ? e.scale : 0.f;
                         float a[NCT];
 #pragma unroll
@@ -455,7 +458,7 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
                         const int tm = m < mine ? __builtin_amdgcn_readfirstlane(e.pad) : 0;   // column tiles this k-step reaches
 #pragma unroll
                         for (int x = 0; x < XT; ++x) {               // B: is its column inside the slot's bin?
-                            if (!(tm & (1 << x))) continue;          // none of the 4 slots reaches this tile: B = 0 (scalar test)
+                            if (!(tm & (1 << x)) || (dbg & 2)) continue;   // none of the 4 slots reaches this tile: B = 0 (scalar test)
                             const int col = 16 * x + n;
                             const float ind = col >= j0 && col < j1 ? 1.f : 0.f;
 #pragma unroll
@@ -465,6 +468,7 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
                 }
             }
         }
+        D2T_KSTAMP(1);
         // partial sums of the NW waves -> LDS; wave w adds the accumulators (c-tile * XT + x) = w mod NW in wave order and stores them
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -504,6 +508,8 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
             }
         }
         __syncthreads();                                             // red and list are free again
+        D2T_KSTAMP(2); D2T_KSTAMP_RT(15);
+        D2T_KSTAMP_PUT(3, (unsigned long long)nks);
     }
 }
 

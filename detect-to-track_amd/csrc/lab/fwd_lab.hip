@@ -3,6 +3,8 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DD2T_LAB lab/fwd_lab.hip -o lab/fwd_lab
 #define D2T_LAB 1
 #include "../d2t_corr_tuned.hip"
+#include "../d2t_corr_fwd_band.hip"     // the rest of the correlation units the tuned one links against
+#include "../d2t_corr_bwd8.hip"
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -30,11 +32,11 @@ int main(int argc, char** argv)
     hipMalloc(&st, (size_t)blocks * 32 * 8);
     hipMemset(st, 0, (size_t)blocks * 32 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(lab_stamps), &st, sizeof(st));
-    for (int i = 0; i < 2 * NS; ++i) corr_fwd_f32(f0[i % NS], f1[i % NS], o[i % NS], B, C, H, W, 8, 1, nullptr, 0);
+    for (int i = 0; i < 2 * NS; ++i) corr_fwd_f32(f0[i % NS], f1[i % NS], o[i % NS], B, C, H, W, 8, 1, nullptr, 0, nullptr);
     hipDeviceSynchronize();
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     hipEventRecord(a);
-    for (int i = 0; i < iters; ++i) corr_fwd_f32(f0[i % NS], f1[i % NS], o[i % NS], B, C, H, W, 8, 1, nullptr, 0);
+    for (int i = 0; i < iters; ++i) corr_fwd_f32(f0[i % NS], f1[i % NS], o[i % NS], B, C, H, W, 8, 1, nullptr, 0, nullptr);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     printf("B=%d C=%d %dx%d: %d workgroups, %.1f us per launch (stamped build)\n", B, C, H, W, blocks, ms * 1000.f / iters);

@@ -16,7 +16,7 @@ from detect_to_track.models import _ext, _native  # noqa: E402
 
 dev = "cuda:0"
 CFGS = [int(x) for x in os.environ.get("SCAN_CFGS", "0,41,42,43,23,22,21,11,16").split(",")]
-SHAPES = [(1, 256, 38, 63), (1, 512, 38, 75), (1, 1024, 38, 75), (1, 2048, 38, 75), (2, 256, 38, 63), (2, 1024, 38, 75)]
+SHAPES = [tuple(int(v) for v in x.split("x")) for x in os.environ["SCAN_SHAPES"].split(",")] if "SCAN_SHAPES" in os.environ else [(1, 256, 38, 63), (1, 512, 38, 75), (1, 1024, 38, 75), (1, 2048, 38, 75), (2, 256, 38, 63), (2, 1024, 38, 75)]
 CHECK = [(1, 40, 38, 63), (2, 24, 21, 24), (1, 17, 5, 20), (1, 33, 38, 75), (3, 16, 13, 41)]
 
 

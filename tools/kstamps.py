@@ -59,6 +59,21 @@ def main():
         run("d2t_lab_pool_fwd_stamps",
             lambda: bench_ops._check(lib.d2t_roipool_fwd_f32(fm.data_ptr(), rois.data_ptr(), out.data_ptr(), R, C, H, W, K, 0, 0, 0, st)),
             ["entry", "planes in LDS", "prefix2d done", "geometry 1 done", "look-ups 1 done", "geometry 2 done", "look-ups 2 done", "end"])
+    if what == "roipool_bwd":
+        R, C, H, W, K = 300, 1024, 38, 63, 7
+        go, gin = torch.rand(R, C, K, K, device=dev), torch.empty(C, H, W, device=dev)
+        rois = torch.from_numpy(bench_ops.random_rois(R, 0)).to(dev)
+        nb = lib.d2t_roipool_bwd_workspace_bytes(R, C, H, W, K, 4)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        call = lambda: bench_ops._check(lib.d2t_roipool_bwd_f32(go.data_ptr(), rois.data_ptr(), gin.data_ptr(), R, C, H, W, K, ws.data_ptr(), nb, 0, st))
+        dbg = lib.d2t_lab_pool_bwd_stamps_dbg
+        dbg.restype, dbg.argtypes = ctypes.c_int, [ctypes.c_int]
+        for bits, name in ((0, "product"), (1, "no gradOut loads"), (2, "no MFMA"), (4, "no list reads in the k-steps"), (3, "no loads, no MFMA"), (7, "none of the three")):
+            assert dbg(bits) == 0
+            print(f"--- ablation {bits}: {name}: op {bench_ops.timed(lambda i: call(), 20, 1):.1f} us")
+            if bits in (0, 1, 7):
+                run("d2t_lab_pool_bwd_stamps", call, ["entry", "k-steps done", "reduced + stored"])
+        assert dbg(0) == 0
     if what.startswith("psroipool_bwd"):
         R, nT = (int(x) for x in (sys.argv[2], sys.argv[3])) if len(sys.argv) > 3 else (3000, 31)
         H, W, K = 38, 75, 7
