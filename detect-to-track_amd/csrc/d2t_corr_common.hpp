@@ -105,7 +105,8 @@ static __device__ __attribute__((noinline)) void strip_repair(int role, int lane
 
 // d2t_corr_fwd_band.hip: forward of small grids, a tile's window split over workgroups (bit-identical); cfg 0 = not taken
 int  corr_fwd_band_config(int B, int H, int W);
-int  corr_fwd_band_f32(int cfg, const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, CellLayout lay, hipStream_t st);
+int  corr_fwd_band_f32(int cfg, int nl, const float* const* fm0, const float* const* fm1, float* const* out, const int* C, int B, int H, int W,
+                       CellLayout lay, hipStream_t st);
 
 // d2t_corr_bwd8.hip
 bool corr_bwd8_supported(int B, int C, int H, int W, int ps, int cs);

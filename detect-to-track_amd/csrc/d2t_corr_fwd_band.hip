@@ -64,6 +64,9 @@ __device__ int band_dbg;                          // ablation bits: 1 no LDS-DMA
 
 namespace {
 
+// the levels of one launch: level l = workgroups [l pad, l pad + per)
+struct BandLevels { const float* fm0[MAXLV]; const float* fm1[MAXLV]; float* out[MAXLV]; int C[MAXLV]; int per, pad; };
+
 constexpr int imin(int a, int b) { return a < b ? a : b; }
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 constexpr int MAXG = WR * NCG;                                       // 95 slot groups of an unclipped tile window
@@ -99,9 +102,16 @@ struct Band {
 // One workgroup: batch item b, tile row u, tile columns [TW vb, TW vb + TW), tile-groups [NB q, NB q + NB).
 template <int TW, int NB, int HT, int KC, int RING, int WL>
 __global__ void __launch_bounds__((TW * NB * HT + WL) * 64)
-k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, float* __restrict__ out,
-                int C, int H, int W, int tiles_i, int tiles_j, int blocks_j, CellLayout lay)
+k_corr_fwd_band(BandLevels lv, int H, int W, int tiles_i, int tiles_j, int blocks_j, CellLayout lay)
 {
+    // level of this workgroup: the levels' workgroups are dealt in blocks of lv.pad (a multiple of 8: a level's workgroups keep the XCD
+    // pattern of a launch of their own), heaviest level first
+    const int level = blockIdx.x / lv.pad, local = blockIdx.x - level * lv.pad;
+    if (local >= lv.per) return;                                     // padding (whole workgroup; nothing before this line syncs)
+    const float* __restrict__ fm0 = lv.fm0[level];
+    const float* __restrict__ fm1 = lv.fm1[level];
+    float* __restrict__ out = lv.out[level];
+    const int C = lv.C[level];
     using S = Band<TW, NB, HT, KC, RING, WL>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -110,7 +120,7 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
     BAND_STAMP(wave == 0, 0); BAND_STAMP_RT(wave == 0, 14); BAND_STAMP(wave == S::WC, 8);
     // logical id (band-set innermost: the band-sets of a block share its FM0 pixels and overlap in window rows; give every
     // XCD a contiguous run of the logical order)
-    int id = xcd_remap(blockIdx.x, gridDim.x);
+    int id = xcd_remap(local, lv.per);
     const int q = id % S::NQ; id /= S::NQ;
     const int vb = id % blocks_j; id /= blocks_j;
     const int u = id % tiles_i, b = id / tiles_i;
@@ -403,15 +413,27 @@ k_corr_fwd_band(const float* __restrict__ fm0, const float* __restrict__ fm1, fl
 }
 
 template <int TW, int NB, int HT, int KC, int RING, int WL>
-int launch_band(const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, CellLayout lay, hipStream_t st)
+int launch_band(int nl, const float* const* fm0, const float* const* fm1, float* const* out, const int* C, int B, int H, int W, CellLayout lay,
+                hipStream_t st)
 {
     using S = Band<TW, NB, HT, KC, RING, WL>;
     const int tiles_i = (H + TP - 1) / TP, tiles_j = (W + TP - 1) / TP, blocks_j = (tiles_j + TW - 1) / TW;
-    const long long nwg = 1LL * B * tiles_i * blocks_j * S::NQ;
-    if (nwg > 0x7fffffffLL) return D2T_ETOOBIG;
+    const long long per = 1LL * B * tiles_i * blocks_j * S::NQ, pad = (per + 7) / 8 * 8;
+    if (nl < 1 || nl > MAXLV || pad * nl > 0x7fffffffLL) return D2T_ETOOBIG;
+    BandLevels lv;
+    lv.per = (int)per; lv.pad = (int)pad;
+    int order[MAXLV];
+    for (int l = 0; l < nl; ++l) order[l] = l;
+    for (int a = 0; a < nl; ++a)                                     // heaviest first (nl <= 4): the long workgroups start first
+        for (int b2 = a + 1; b2 < nl; ++b2)
+            if (C[order[b2]] > C[order[a]]) { const int t = order[a]; order[a] = order[b2]; order[b2] = t; }
+    for (int l = 0; l < MAXLV; ++l) {
+        const int src = order[l < nl ? l : nl - 1];
+        lv.fm0[l] = fm0[src]; lv.fm1[l] = fm1[src]; lv.out[l] = out[src]; lv.C[l] = C[src];
+    }
     auto kfn = k_corr_fwd_band<TW, NB, HT, KC, RING, WL>;
     D2T_ENSURE_DYNAMIC_LDS(kfn, S::LDS * 4);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nwg), dim3(S::THREADS), S::LDS * 4, st, fm0, fm1, out, C, H, W, tiles_i, tiles_j, blocks_j, lay);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(pad * nl)), dim3(S::THREADS), S::LDS * 4, st, lv, H, W, tiles_i, tiles_j, blocks_j, lay);
     return launch_status();
 }
 
@@ -438,10 +460,13 @@ int corr_fwd_band_config(int B, int H, int W)
     return n4 > 256 && n5 <= 256 ? 1251 : 141;
 }
 
-int corr_fwd_band_f32(int cfg, const float* fm0, const float* fm1, float* out, int B, int C, int H, int W, CellLayout lay, hipStream_t st)
+// nl levels of one spatial shape in ONE launch (the tracker's three B = 1 calls, correlation_tracker.py:68-70): the workgroups of the next
+// level start as CUs come free instead of behind a launch boundary.
+int corr_fwd_band_f32(int cfg, int nl, const float* const* fm0, const float* const* fm1, float* const* out, const int* C, int B, int H, int W,
+                      CellLayout lay, hipStream_t st)
 {
     switch (cfg) {
-#define D2T_BAND_CASE(id, TW, NB, HT, KC, RING, WL) case id: return launch_band<TW, NB, HT, KC, RING, WL>(fm0, fm1, out, B, C, H, W, lay, st);
+#define D2T_BAND_CASE(id, TW, NB, HT, KC, RING, WL) case id: return launch_band<TW, NB, HT, KC, RING, WL>(nl, fm0, fm1, out, C, B, H, W, lay, st);
         D2T_BAND_CASE(141, 4, 1, 1, 16, 3, 4)
         D2T_BAND_CASE(1251, 5, 1, 2, 16, 3, 6)
         D2T_BAND_CASE(142, 4, 2, 1, 16, 3, 4)

@@ -710,11 +710,14 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
     const long long strip_blocks = 1LL * B * tiles_j * nseg;
 #ifdef D2T_ENV_KNOBS
     if (lab_env_int("D2T_BAND_CFG", -1) > 0) {       // scan builds: the band-split kernel on any grid (tools/band_scan.py)
-        for (int l = 0; l < nl; ++l) {
-            const int rc = corr_fwd_band_f32(lab_env_int("D2T_BAND_CFG", -1), fm0[l], fm1[l], out[l], B, C[l], H, W, lay, st);
-            if (rc != D2T_OK) return rc;
+        if (lab_env_int("D2T_BAND_LEVEL_LAUNCHES", 0)) {                 // A/B: one launch per level
+            for (int l = 0; l < nl; ++l) {
+                const int rc = corr_fwd_band_f32(lab_env_int("D2T_BAND_CFG", -1), 1, fm0 + l, fm1 + l, out + l, C + l, B, H, W, lay, st);
+                if (rc != D2T_OK) return rc;
+            }
+            return D2T_OK;
         }
-        return D2T_OK;
+        return corr_fwd_band_f32(lab_env_int("D2T_BAND_CFG", -1), nl, fm0, fm1, out, C, B, H, W, lay, st);
     }
 #endif
     if (strip_blocks >= 192) {                       // enough segments to give (nearly) every CU one
@@ -751,11 +754,14 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
     }
     // small grids: the tile's WINDOW split over workgroups (d2t_corr_fwd_band.hip), one launch per level
     if (const int cfg = corr_fwd_band_config(B, H, W)) {
-        for (int l = 0; l < nl; ++l) {
-            const int rc = corr_fwd_band_f32(cfg, fm0[l], fm1[l], out[l], B, C[l], H, W, lay, st);
-            if (rc != D2T_OK) return rc;
+        if (lab_env_int("D2T_BAND_LEVEL_LAUNCHES", 0)) {                 // scan builds, A/B: one launch per level
+            for (int l = 0; l < nl; ++l) {
+                const int rc = corr_fwd_band_f32(cfg, 1, fm0 + l, fm1 + l, out + l, C + l, B, H, W, lay, st);
+                if (rc != D2T_OK) return rc;
+            }
+            return D2T_OK;
         }
-        return D2T_OK;
+        return corr_fwd_band_f32(cfg, nl, fm0, fm1, out, C, B, H, W, lay, st);
     }
 #ifndef D2T_ENV_KNOBS
     return D2T_EINVAL;                               // not reached: corr_fwd_band_config names a shape for every grid of the envelope

@@ -1159,6 +1159,8 @@ constexpr int PR_WAVES = KT, PR_THREADS = PR_WAVES * 64;             // 448
 constexpr int PR_EC = 32;                                            // hits per chunk = 8 k-steps
 constexpr int PR_TP = 32;                                            // targets padded to two c-tiles
 constexpr int PR_MAXHITS = 4096;                                     // LDS hit list (ints); more hits: further rounds
+constexpr int PR_SCAN = 9;                                           // passes of 448 RoIs per round: 63 (pass, wave) counters, one wave-scan
+static_assert(PR_SCAN * PR_WAVES <= 63 && PR_SCAN * PR_THREADS <= PR_MAXHITS, "hit scan");
 
 // bin axes of every RoI, once: rowb[i][r] = i0 | i1 << 16 of cell row i (coalesced for the scan of a task), colb[r][j] = j0 | j1 << 16
 // of cell column j (32 bytes per RoI).  ps_roipool_cuda.cu:36-54 through the same bin_axis as every other kernel.
@@ -1182,17 +1184,22 @@ k_ps_axes(const float* __restrict__ rois, int* __restrict__ rowb, int* __restric
 template <int XT, int NCT>
 __global__ void __launch_bounds__(PR_THREADS)
 k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, const int* __restrict__ rowb, const int* __restrict__ colb,
-              float* __restrict__ part, int R, int nT, int H, int W)
+              float* __restrict__ part, int R, int nT, int H, int W, int nseg, int rps)
 {
     __shared__ int hits[PR_MAXHITS];
-    __shared__ int wsum[PR_WAVES + 1];
+    __shared__ int wcnt[64];                                         // hits per (pass, wave) of a round's scan
     __shared__ __attribute__((aligned(16))) float A[2][KT][PR_EC][PR_TP];   // 2 x 28 KB
     __shared__ int ejb[2][PR_EC][KT + 1];
     __shared__ float esc[2][PR_EC][KT + 1];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // one task per workgroup, numbered from the middle rows outwards: they carry the most hits and start first
-    const int task = blockIdx.x, p = task / KT, i = task - p * KT, d = (p + 1) >> 1;
+    // a task (map row y, bin row i) is dealt to nseg workgroups by RoI RANGE -- workgroup `seg` walks RoIs [seg rps, seg rps + rps) and
+    // writes its own partial planes; the gather adds the partials in ascending order.  (Thousands of RoIs: one workgroup per task was
+    // 266 workgroups walking ~290 hits each, one after the other, with the chip a third full.)
+    const int seg = blockIdx.x % nseg, task = blockIdx.x / nseg, p = task / KT, i = task - p * KT, d = (p + 1) >> 1;
+    const int r_lo = seg * rps, r_hi = r_lo + rps < R ? r_lo + rps : R;
+    part += (size_t)seg * nT * KK * H * W;
     const int y = (p & 1) ? (H - 1) / 2 + d : (H - 1) / 2 - d;
     const int j = wave;                                              // this wave's bin column
     D2T_KSTAMP(0); D2T_KSTAMP_RT(14);
@@ -1206,27 +1213,40 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, co
     const unsigned gout_bytes = (unsigned)((size_t)R * nT * KK * 4);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, gout_bytes, 0x00020000);
 
-    for (int rbase = 0; rbase < R; rbase += PR_MAXHITS) {            // one round unless more than 4096 RoIs
-        const int rend = R - rbase < PR_MAXHITS ? R : rbase + PR_MAXHITS;
-        // ---- 1. hit list of RoIs [rbase, rend): ascending
-        int total = 0;                                               // uniform
-        for (int r0 = rbase; r0 < rend; r0 += PR_THREADS) {
-            const int r = r0 + tid;
+    for (int rbase = r_lo; rbase < r_hi; rbase += PR_SCAN * PR_THREADS) {   // one round unless more than 4032 RoIs in the range
+        const int rend = r_hi - rbase < PR_SCAN * PR_THREADS ? r_hi : rbase + PR_SCAN * PR_THREADS;
+        // ---- 1. hit list of RoIs [rbase, rend): ascending.  Thread tid tests RoIs rbase + 448 p + tid, p < 9, with all its loads in
+        // flight together; the 9 x 7 (pass, wave) counts meet at ONE barrier and every wave scans the 63 of them by itself.  (A barrier
+        // pair per pass of 448 RoIs, as at first, was 1.6 k cycles per pass: 11 k cycles for 3000 RoIs.)
+        if (rbase != r_lo) __syncthreads();                          // the previous round's counts and hits have been consumed
+        unsigned long long mk[PR_SCAN];
+        int inb = 0;
+#pragma unroll
+        for (int ps = 0; ps < PR_SCAN; ++ps) {
+            const int r = rbase + ps * PR_THREADS + tid;
             bool in = false;
             if (r < rend) {
                 const int rb = rowi[r];
                 in = y >= (rb & 0xffff) && y < (rb >> 16);
             }
-            const unsigned long long m = __ballot(in);
-            const int below = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            __syncthreads();                                         // wsum of the previous pass consumed
-            if (lane == 0) wsum[wave] = __builtin_popcountll(m);
-            __syncthreads();
-            int base = 0, cnt = 0;
+            mk[ps] = __ballot(in);
+            inb |= in ? 1 << ps : 0;
+            if (lane == 0) wcnt[ps * PR_WAVES + wave] = __builtin_popcountll(mk[ps]);
+        }
+        __syncthreads();
+        const int mine = lane < PR_SCAN * PR_WAVES ? wcnt[lane] : 0;
+        int inc = mine;
 #pragma unroll
-            for (int w = 0; w < PR_WAVES; ++w) { const int v = wsum[w]; base += w < wave ? v : 0; cnt += v; }
-            if (in) hits[total + base + below] = r;
-            total += cnt;
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const int o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        const int exc = inc - mine;
+        const int total = __builtin_amdgcn_readlane(inc, 63);        // uniform
+#pragma unroll
+        for (int ps = 0; ps < PR_SCAN; ++ps) {
+            const int base = __builtin_amdgcn_readlane(exc, ps * PR_WAVES + wave);
+            if (inb & (1 << ps)) hits[base + __builtin_popcountll(mk[ps] & ((1ull << lane) - 1ull))] = rbase + ps * PR_THREADS + tid;
         }
         __syncthreads();
         D2T_KSTAMP(1);
@@ -1344,7 +1364,7 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, co
                     const int t = 16 * ct + (e >> 4), xx = 16 * x + (e & 15);
                     if (t >= nT || xx >= W) continue;
                     float a = 0.f;
-                    for (int r = 0; r < R; ++r) {
+                    for (int r = r_lo; r < r_hi; ++r) {
                         const Bounds cb = psroi_cell<float>(rois + 4 * (size_t)r, i, j, H, W, KT);
                         const int nn = (cb.i1 - cb.i0) * (cb.j1 - cb.j0);
                         if (y >= cb.i0 && y < cb.i1 && xx >= cb.j0 && xx < cb.j1)
@@ -1363,21 +1383,34 @@ static bool psroipool_bwd_rows_supported(int R, int nT, int H, int W, int k)
            1LL * R * nT * KK * 4 < 0x7ffffff0LL && 1LL * nT * KK * H * W < 0x7fffffffLL && 1LL * KT * H < 0x7fffffffLL;
 }
 
-// workspace: planes (nT*49, H*W) | rowb (7, R) | colb (R, 8)
+// RoI ranges per task.  Every workgroup pays ~20 k cycles whatever it walks (hit scan, first chunk, plane stores) and two fit a CU, so
+// a range only pays where a task's walk is long: thousands of RoIs.  tools/ps_segs_scan.py, 38 x 75, us by ranges 1 / 2 / 3 / 4 (scan
+// build): R 3000 nT 4  58 / 44 / 51 / 49, nT 8  60 / 47 / 55 / 55, nT 16  66 / 52 / 65 / 64, nT 31  87 / 93 / 114 / 114;
+// R 1000 nT 4  27 / 25 / 31 / 33, nT 16  35 / 36 / 44 / 49; R 300 nT 21  31 / 41 / 51 / 63 (profiles/r05_e_ps_rows_roi_ranges.txt).
+static int ps_rows_segs(int R, int nT)
+{
+    const int forced = lab_env_int("D2T_PS_SEGS", 0);                // scan builds only
+    if (forced > 0) return forced;
+    return R >= 1400 && nT <= 16 ? 2 : 1;
+}
+
+// workspace: partial planes (segs, nT*49, H*W) | rowb (7, R) | colb (R, 8)
 static size_t psroipool_bwd_rows_ws_bytes(int R, int nT, int H, int W, int k)
 {
-    return psroipool_bwd_rows_supported(R, nT, H, W, k) ? align256((size_t)nT * KK * H * W * 4) + align256((size_t)KT * R * 4) + align256((size_t)R * 32) : 0;
+    return psroipool_bwd_rows_supported(R, nT, H, W, k)
+               ? ps_rows_segs(R, nT) * align256((size_t)nT * KK * H * W * 4) + align256((size_t)KT * R * 4) + align256((size_t)R * 32) : 0;
 }
 
 static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, void* ws, hipStream_t st)
 {
     char* w = static_cast<char*>(ws);
-    float* part = reinterpret_cast<float*>(w); w += align256((size_t)nT * KK * H * W * 4);
+    const int nseg = ps_rows_segs(R, nT), rps = (R + nseg - 1) / nseg;
+    float* part = reinterpret_cast<float*>(w); w += nseg * align256((size_t)nT * KK * H * W * 4);
     int* rowb = reinterpret_cast<int*>(w); w += align256((size_t)KT * R * 4);
     int* colb = reinterpret_cast<int*>(w);
     hipLaunchKernelGGL(k_ps_axes, dim3((R + 255) / 256), dim3(256), 0, st, rois, rowb, colb, R, H, W);
     const int xt = (W + 15) / 16, ntasks = KT * H;
-#define D2T_LAUNCH_PR(XTV, NCTV) hipLaunchKernelGGL((k_ps_bwd_rows<XTV, NCTV>), dim3(ntasks), dim3(PR_THREADS), 0, st, gout, rois, rowb, colb, part, R, nT, H, W)
+#define D2T_LAUNCH_PR(XTV, NCTV) hipLaunchKernelGGL((k_ps_bwd_rows<XTV, NCTV>), dim3(ntasks * nseg), dim3(PR_THREADS), 0, st, gout, rois, rowb, colb, part, R, nT, H, W, nseg, rps)
 #define D2T_LAUNCH_PR_X(NCTV) { if (xt <= 4) D2T_LAUNCH_PR(4, NCTV); else if (xt <= 5) D2T_LAUNCH_PR(5, NCTV); else D2T_LAUNCH_PR(8, NCTV); }
     if (nT <= 16) D2T_LAUNCH_PR_X(1) else D2T_LAUNCH_PR_X(2)
 #undef D2T_LAUNCH_PR_X
@@ -1385,7 +1418,7 @@ static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* g
     int rc = launch_status();
     if (rc != D2T_OK) return rc;
     const int HW = H * W;
-    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW);
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW, nseg);
     return launch_status();
 }
 
@@ -1423,7 +1456,8 @@ static int ps_bwd_design(int R, int nT, int H, int W, int k)
     // measured grid R in {300..3000} x nT in {4..31} on a 38x75 map (tools/ps_scan.py, profiles/r02_b_ps_bwd_scan_*):
     // the GEMM wins from 12 targets up at every R (R=300 nT=16: 33 vs 40 us; R=3000 nT=31: 73 vs 148 sorted / 278 planes)
     // and from 8 targets at R >= 1000; the plane kernels keep the small shapes (R=300 nT=4: 15 vs 25 us)
-    if (rw && f == 0 && !(g && nT >= 12 && R >= 1500)) return 3;       // round 5: the row form -- except many targets x thousands of RoIs (R = 3000 nT = 31: 79 against 71 us)
+    if (rw && f == 0 && !(g && nT > 16 && R >= 1500)) return 3;        // round 5: the row form -- except more than 16 targets (two c-tiles per wave) x thousands of RoIs
+                                                                       // (R 3000 nT 31: 87 against 71 us, R 1500 nT 31: 57 against 53; R 3000 nT 16: 52 against 65)
     if (g && (nT >= 12 || (nT >= 8 && R >= 1000) || !p)) return 2;
     if (s && (!p || (nT >= PS_SORTED_MIN_TARGETS && 1LL * R * nT >= PS_SORTED_MIN_WORK))) return 1;
     return p ? 0 : (s ? 1 : 0);

@@ -330,6 +330,10 @@ static bool sat2_anyk(int C, int H, int W, int k)
     return k >= 1 && k <= S2_MAXK && sat_layout(2, H, W, 4 * k > GEO8 ? 4 * k : GEO8).bytes <= (size_t)LDS_MAX;
 }
 
+// Round 5, measured and dropped: a forward for a HANDFUL of RoIs (the tracker pools ~8 boxes of a 1891-channel map) that stages the
+// boxes of 16 channels through LDS with coalesced row loads and adds the bins from LDS in the reference's order (bit-identical): 25.2 us at
+// R = 8 against 21.7 us for the thread-per-output kernel that capi.hip keeps for R < 32 (profiles/r05_e_roipool_few_rois_lost.txt: with every
+// workgroup resident the box loads alone take 24 k cycles -- the op is bound by first-touch fills of partly used lines, not by its lanes).
 bool roipool_fwd_supported(int R, int C, int H, int W, int k)
 {
     if (!(R >= 1 && C >= 1 && H >= 1 && W >= 1 && H <= 255 && W <= 255)) return false;
