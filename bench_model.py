@@ -239,7 +239,7 @@ def main(argv=None):
     line = {
         "bench": "DetectTrack training step (BASELINE config %d)" % (4 if world == 1 else 5), "n_gpus": world, "scaling": "weak",
         "parallelism": f"dp{world}" if world > 1 else "single", "dtype": "f32", "data": "synthetic",
-        "weights": "random", "process_group": args.backend if dist_on else None, "gradient_buckets": buckets is not None, "pairs_batched": not args.per_pair, "tracker_fast_forward": not args.exact_tracker, "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find),
+        "weights": "random", "process_group": args.backend if dist_on else None, "gradient_buckets": buckets is not None, "pairs_batched": not args.per_pair, "tracker_fast_forward": bool(args.fast_tracker) and not args.exact_tracker, "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find),
         "config": {"workload": f"detecttrack_{args.backbone}_B{B}pairs_3x{H}x{W}", "pairs": B, "frame": [3, H, W],
                    "c4": [fh, fw], "regions_per_frame": R, "tracked_boxes": Rt, "anchors": n_anchor},
         "ms_per_step": step_ms, "pairs_per_s": world * B / step_ms * 1e3, "pairs_per_gpu": B, "finite": finite, "max_abs_activation": amax,
