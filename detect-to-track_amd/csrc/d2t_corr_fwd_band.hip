@@ -1,5 +1,5 @@
-// d2t_corr_fwd_band.hip -- gfx950-tuned f32 PointwiseCorrelation forward for SMALL grids (d_max = 8, stride 1): the
-// model's B = 1 pairs (correlation_tracker.py:57-70) and BASELINE config 2.  Bit-identical to the reference
+// d2t_corr_fwd_band.hip -- gfx950-tuned f32 PointwiseCorrelation forward for SMALL and MEDIUM grids (d_max = 8, stride 1): the
+// model's B = 1 pairs (correlation_tracker.py:57-70), BASELINE config 2, B <= 5 at the model's maps.  Bit-identical to the reference
 // (pointwise_correlation_cuda.cu:84-107): every output cell is ONE ascending-channel chain of v_mfma_f32_16x16x4_f32,
 // exactly as in d2t_corr_tuned.hip -- parallelism comes from splitting a tile's WINDOW over workgroups, never its channels.
 //
@@ -20,9 +20,13 @@
 //     where the matrix work is 0.43 us.  So WL dedicated LOADER waves issue every DMA instruction; the computing
 //     waves' stream is LDS reads and MFMAs only.  (4-byte-per-lane DMA -- 256 contiguous bytes per instruction -- is
 //     no cheaper per instruction: 2.4x slower in all.)
-//   * code that runs once per wave is not free: a straight-from-the-registers epilogue (12-16 exec-masked stores, 4 KB
-//     of straight-line code fetched cold by every wave of the chip at the same moment) took 4.3 k cycles of a 30 k-cycle
-//     kernel.  The epilogue is a scatter into a per-task LDS patch and a short store loop.
+//   * code that runs once per wave is not free: the first straight-from-the-registers epilogue (16 exec-masked dword stores, 4 KB of
+//     straight-line code fetched cold by every wave of the chip at the same moment) took 4.3 k cycles of a 30 k-cycle kernel; a scatter
+//     into a per-task LDS patch + a store loop took 11.8 k with one wave per task.  The epilogue is 16-byte stores straight from the
+//     accumulators where a wave owns a whole task in the reference layout, and the LDS patch -- consecutive lanes on consecutive
+//     cells / pixels -- for two-wave tasks and for the channel-major layout.
+//   * at the METRIC shape (B = 8) this kernel loses to the 5-tile segments of d2t_corr_tuned.hip: 63.7-96.8 against 47 us, its matrix
+//     work alone 35 us (profiles/r05_d_band_ablation_headline_shape.txt); it serves every grid below that kernel's threshold.
 // Staging: ring of RING chunk images filled by LDS-DMA, counted vmcnt waits on the loader side, ONE barrier per chunk
 // for both roles, placed in the middle of a chunk's MFMAs so that the next chunk's fragments are fetched under its
 // second half.  A band's cells of a pixel are a contiguous run of its 17 x 17 block; the structural zeros (cj = 16,
