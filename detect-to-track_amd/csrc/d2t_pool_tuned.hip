@@ -207,7 +207,8 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const float* __restrict__ rois, 
 // 8.0 k); not raising the dynamic-LDS limit (still one workgroup per CU).
 // ---------------------------------------------------------------------------------------
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-constexpr int S2_THREADS = 1024;             // two workgroups per CU (45 KB of LDS each); 512 threads x 4 per CU measured 35.5 us against 32.8
+constexpr int S2_THREADS = 1024;             // 56 KB of LDS per workgroup: the runtime's occupancy query says two per CU, the clocks show one at a time;
+                                             // 832 / 768 / 640 / 512 threads per workgroup: 33.4 / 31.4 / 33.1 / 35.5 us against 31.8 (round 5)
 constexpr int S2_ACTIVE = 980;               // 20 RoIs x 49 bins per pass
 constexpr int S2_MAXK = 16;                  // run-time bin counts the interleaved kernel takes (4k bytes of geometry per RoI <= 64)
 
@@ -334,6 +335,19 @@ static bool sat2_anyk(int C, int H, int W, int k)
 // boxes of 16 channels through LDS with coalesced row loads and adds the bins from LDS in the reference's order (bit-identical): 25.2 us at
 // R = 8 against 21.7 us for the thread-per-output kernel that capi.hip keeps for R < 32 (profiles/r05_e_roipool_few_rois_lost.txt: with every
 // workgroup resident the box loads alone take 24 k cycles -- the op is bound by first-touch fills of partly used lines, not by its lanes).
+#ifdef D2T_ENV_KNOBS
+// scan builds: what the runtime says about the residency of the interleaved summed-area kernel (tools/kstamps.py roipool_occupancy)
+extern "C" int d2t_lab_roipool_fwd_occupancy(int H, int W, int threads, int* blocks, int* regs, int* static_lds, int* dyn_lds)
+{
+    const SatLayout L = sat_layout(2, H, W, GEO8);
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_roipool_fwd_sat2<KT>));
+    if (e != hipSuccess) return (int)e;
+    *regs = fa.numRegs; *static_lds = (int)fa.sharedSizeBytes; *dyn_lds = (int)L.bytes;
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, k_roipool_fwd_sat2<KT>, threads, L.bytes);
+}
+#endif
+
 bool roipool_fwd_supported(int R, int C, int H, int W, int k)
 {
     if (!(R >= 1 && C >= 1 && H >= 1 && W >= 1 && H <= 255 && W <= 255)) return false;
