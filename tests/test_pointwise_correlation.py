@@ -164,6 +164,49 @@ def test_matches_live_reference(case, impl, ref_modules):
     torch.testing.assert_close(g1, r1, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", [(1, 256, 38, 63), (1, 300, 38, 75), (2, 40, 38, 63), (3, 72, 38, 63), (4, 33, 38, 63), (5, 24, 38, 63),
+                                  (3, 48, 38, 75), (5, 17, 38, 75), (2, 130, 38, 75), (1, 19, 5, 20), (4, 9, 21, 44), (3, 16, 13, 41)], ids=str)
+def test_band_split_forward_every_dispatch_shape(case, ref_modules):
+    """The window-split forward (csrc/d2t_corr_fwd_band.hip; round 5) takes every grid below the 5-tile segment kernel's threshold:
+    one workgroup per CU at the model's B = 1 maps (four / five tiles side by side, one / two waves per task), several rounds at
+    B = 2, the medium grids B = 3 .. 5 (band-sets of one or two tile-groups), short and narrow maps.  Bit-identical to the
+    reference's kernels in the reference layout and, through the level entry point, in the channel-major layout (the structural
+    zeros and the bytes around the block included); deterministic."""
+    from detect_to_track.models import _ext
+    ref_corr = ref_modules[0]
+    B, C, H, W = case
+    torch.manual_seed(B * 100 + C)
+    fm0, fm1 = torch.randn(B, C, H, W, device=DEV), torch.randn(B, C, H, W, device=DEV)
+    ref = ref_corr.pointwise_correlation_forward(fm0, fm1, 8, 1)
+    out = _ext.pointwise_correlation_forward(fm0, fm1, 8, 1, 0)
+    assert torch.equal(out, ref), f"max |delta| {(out - ref).abs().max().item()}"
+    assert torch.equal(out, _ext.pointwise_correlation_forward(fm0, fm1, 8, 1, 2))        # tuned kernels demanded: the same kernel
+    buf = torch.full((B, 289 + 9, H, W), float("nan"), device=DEV)
+    _ext.pointwise_correlation_levels_forward([fm0], [fm1], 8, 1, out=(buf, 4), impl=0)
+    cm = buf[:, 4:293].reshape(B, 17, 17, H, W).permute(0, 3, 4, 1, 2).contiguous()
+    assert torch.equal(cm, ref)
+    assert bool(torch.isnan(buf[:, :4]).all()) and bool(torch.isnan(buf[:, 293:]).all())
+
+
+def test_band_split_forward_four_levels_one_launch(ref_modules):
+    """Up to four levels of one spatial shape go out as ONE launch of the band kernel (heaviest first, each level's workgroups
+    padded to a multiple of 8): every level bit-identical to its own call, in the order the caller gave them, both layouts."""
+    from detect_to_track.models import _ext
+    ref_corr = ref_modules[0]
+    B, H, W = 1, 38, 75
+    Cs = [24, 200, 8, 65]                                                                   # not sorted: the launch re-orders, the outputs must not
+    torch.manual_seed(77)
+    fm0 = [torch.randn(B, c, H, W, device=DEV) for c in Cs]
+    fm1 = [torch.randn(B, c, H, W, device=DEV) for c in Cs]
+    refs = [ref_corr.pointwise_correlation_forward(a, b, 8, 1) for a, b in zip(fm0, fm1)]
+    buf = torch.full((B, 4 * 289 + 5, H, W), float("nan"), device=DEV)
+    _ext.pointwise_correlation_levels_forward(fm0, fm1, 8, 1, out=(buf, 2), impl=0)
+    for l, ref in enumerate(refs):
+        cm = buf[:, 2 + 289 * l:2 + 289 * (l + 1)].reshape(B, 17, 17, H, W).permute(0, 3, 4, 1, 2).contiguous()
+        assert torch.equal(cm, ref), f"level {l}"
+    assert bool(torch.isnan(buf[:, :2]).all()) and bool(torch.isnan(buf[:, 2 + 4 * 289:]).all())
+
+
 def test_headline_golden():
     """B=8 C=256 38x63 d=8 against values the REFERENCE's kernels produced for the same seeded inputs
     (tests/golden/corr_headline_subsample.npz: a seeded subsample of cells and gradient elements,

@@ -214,6 +214,30 @@ def test_nonfinite_gradout_gemm_backward(case):
     torch.testing.assert_close(got[fin], want[fin], rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("case", [(1500, 4, 38, 75), (3000, 16, 38, 63), (1401, 7, 19, 40), (4500, 2, 38, 75)], ids=str)
+def test_row_form_backward_roi_ranges(case, oracle):
+    """The row-form backward (k_ps_bwd_rows, round 5) deals a task's RoIs to TWO workgroups from 1,400 RoIs up (<= 16 targets) and the
+    gather adds the partial planes; 4,500 RoIs also take a second round of the hit scan (4,032 RoIs per round).  Signed data against the
+    yardstick with the reference's f32 terms added in double (ps_roipool_cuda.cu:120-139): 1e-5 of the sum of |terms|; Inf / NaN in
+    gradOut: the pattern and the finite values of the reference-order kernels; deterministic."""
+    from detect_to_track.models import _ext
+    R, nT, H, W = case
+    rng = np.random.default_rng(R + nT)
+    rois = random_rois(R, 5)
+    gout = rng.standard_normal((R, nT, 7, 7)).astype(np.float32)
+    got = _ext.ps_roipool_backward(_t(gout), _t(rois), H, W)
+    want, mass = oracle.psroipool_bwd_acc64(gout, rois, H, W)
+    oracle.assert_within_contract(_n(got), want, mass, 1e-5, "gradFM, row form with RoI ranges")
+    assert torch.equal(got, _ext.ps_roipool_backward(_t(gout), _t(rois), H, W))
+    gout[3, 1, 2, 2] = np.inf; gout[R - 1, nT - 1, 6, 0] = -np.inf; gout[R // 2 + 1, 0, 0, 6] = np.nan
+    got = _ext.ps_roipool_backward(_t(gout), _t(rois), H, W)
+    ref = _ext.ps_roipool_backward(_t(gout), _t(rois), H, W, 1)
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    assert torch.equal(torch.isposinf(got), torch.isposinf(ref)) and torch.equal(torch.isneginf(got), torch.isneginf(ref))
+    fin = torch.isfinite(ref)
+    torch.testing.assert_close(got[fin], ref[fin], rtol=2e-5, atol=2e-4)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("case", [(300, 21, 38, 63, 6, "random"), (40, 31, 20, 31, 3, "random"), (17, 5, 9, 14, 14, "random"), (9, 3, 7, 5, 1, "random"),
                                   (300, 4, 38, 63, 8, "adversarial"), (520, 9, 12, 17, 2, "random"), (12, 6, 20, 20, 3, "huge")], ids=str)
