@@ -335,6 +335,8 @@ static bool sat2_anyk(int C, int H, int W, int k)
 // boxes of 16 channels through LDS with coalesced row loads and adds the bins from LDS in the reference's order (bit-identical): 25.2 us at
 // R = 8 against 21.7 us for the thread-per-output kernel that capi.hip keeps for R < 32 (profiles/r05_e_roipool_few_rois_lost.txt: with every
 // workgroup resident the box loads alone take 24 k cycles -- the op is bound by first-touch fills of partly used lines, not by its lanes).
+// Nor did a thread-per-output kernel whose bin rows are fetched by eight independent loads before they are added (20.2 against 21.9 us at R = 8,
+// 28.9 against 26.0 at R = 16): the generic kernel is not waiting on a dependent chain either.
 #ifdef D2T_ENV_KNOBS
 // scan builds: what the runtime says about the residency of the interleaved summed-area kernel (tools/kstamps.py roipool_occupancy)
 extern "C" int d2t_lab_roipool_fwd_occupancy(int H, int W, int threads, int* blocks, int* regs, int* static_lds, int* dyn_lds)

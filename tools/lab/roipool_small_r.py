@@ -9,7 +9,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
 import bench_ops  # noqa: E402
 from detect_to_track.models import _ext  # noqa: E402
@@ -34,7 +34,7 @@ for (R, C, H, W, k) in [(8, 1891, 38, 75, 7), (5, 33, 21, 40, 7), (3, 17, 38, 75
     print(f"check R={R} C={C} {H}x{W} k={k}: {'bit-identical' if same else 'MISMATCH'}", flush=True)
 for R in (8, 16, 32, 64, 128):
     row = []
-    for name, env in (("boxes via LDS", {"D2T_ROI_FEW_MAXR": "100000", "D2T_ROI_FEW_OFF": "0"}), ("thread per output", {"D2T_ROI_FEW_MAXR": "100000", "D2T_ROI_FEW_OFF": "1"}),
+    for name, env in (("row-batched loads", {"D2T_ROI_FEW_MAXR": "100000", "D2T_ROI_FEW_OFF": "0"}), ("thread per output", {"D2T_ROI_FEW_MAXR": "100000", "D2T_ROI_FEW_OFF": "1"}),
                       ("summed-area", {"D2T_ROI_FEW_MAXR": "0", "D2T_ROI_FEW_OFF": "0"})):
         os.environ.update(env)
         e = bench_ops.measure_roipool(dev, R, 1891, 38, 75, 0, 30, st)
