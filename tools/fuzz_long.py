@@ -10,7 +10,8 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 bad = 0
 for it in range(N):
-    R = int(rng.integers(1, 700)); H = int(rng.integers(1, 60)); W = int(rng.integers(1, 129))
+    R = int(rng.integers(1, 700)) if it % 5 else int(rng.integers(1400, 5000))     # every fifth case: thousands of RoIs (PSROIPool row form with RoI ranges)
+    H = int(rng.integers(1, 60)); W = int(rng.integers(1, 129))
     if it % 2 == 0:
         C = int(rng.integers(1, 200))
         fm = torch.from_numpy(rng.random((C, H, W), dtype=np.float32)).to(DEV)
