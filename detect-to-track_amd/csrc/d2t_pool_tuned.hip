@@ -200,15 +200,14 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const float* __restrict__ rois, 
 // addresses conflict less than 8-byte ones (the planar kernel's SQ_LDS_BANK_CONFLICT is 52 % of its LDS time).
 // Round 5, what the workgroup's clocks say (tools/kstamps.py, profiles/r05_c_kstamps_roipool_fwd_*.txt; config 3, cycles per workgroup):
 // planes into LDS 8.6 k, prefix2d 8.0 k, geometry of 240 RoIs 4.1 k, look-ups 8.1 k, geometry of the last 60 5.4 k, look-ups 3.0 k =
-// 37.7 k = 16 us -- and only 256 of the 512 workgroups are resident at a time (one per CU although two fit by LDS, waves and registers:
-// the 100 MHz clock at entry / exit shows two rounds), so the op is two rounds of latency-bound phases, not its 54 % LDS bank
-// conflicts.  Measured and dropped: the geometry of all RoIs evaluated under the plane loads' latency (workgroup 37.7 k -> 29.7 k
-// cycles, but the op 31.4 -> 34.2 us: the second round starts later); the 2-D prefix as wave-wide f64 row scans (12.7 k cycles against
-// 8.0 k); not raising the dynamic-LDS limit (still one workgroup per CU).
+// 37.7 k = 16 us, two workgroups per CU (512 in all).  The stamped build runs them one at a time, the product kernel (60 VGPRs) two at a time --
+// csrc/lab/occ_lab: a CU holds two 1,024-thread workgroups of 56 KB up to 64 VGPRs -- which changes little: prefix and look-ups are LDS-bound and
+// co-resident workgroups share the LDS pipe.  Measured and dropped: the geometry of all RoIs evaluated under the plane loads' latency (workgroup
+// 37.7 k -> 29.7 k cycles, but the op 31.4 -> 34.2 us); the 2-D prefix as wave-wide f64 row scans (12.7 k cycles against 8.0 k); workgroups of
+// 832 / 768 / 640 / 512 threads (33.4 / 31.4 / 33.1 / 35.5 us against 31.8).
 // ---------------------------------------------------------------------------------------
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-constexpr int S2_THREADS = 1024;             // 56 KB of LDS per workgroup: the runtime's occupancy query says two per CU, the clocks show one at a time;
-                                             // 832 / 768 / 640 / 512 threads per workgroup: 33.4 / 31.4 / 33.1 / 35.5 us against 31.8 (round 5)
+constexpr int S2_THREADS = 1024;             // 56 KB of LDS per workgroup, 60 VGPRs: two workgroups per CU
 constexpr int S2_ACTIVE = 980;               // 20 RoIs x 49 bins per pass
 constexpr int S2_MAXK = 16;                  // run-time bin counts the interleaved kernel takes (4k bytes of geometry per RoI <= 64)
 
