@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Tracker glue alone (three correlations + cat + ROIPool: unfused, fused exact, fused FAST), 40 iterations each -- the A/B partner of
+D2T_BAND_LEVEL_LAUNCHES=1 in a scan build (one launch per level against one launch for all levels)."""
 import sys, json
 sys.path.insert(0, "."); sys.path.insert(0, "detect-to-track_amd")
 import bench_ops
