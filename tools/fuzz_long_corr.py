@@ -11,6 +11,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = 0
 for it in range(N):
     B = int(rng.integers(1, 10)); C = int(rng.integers(1, 300)); H = int(rng.integers(1, 50)); W = int(rng.integers(20, 100))
+    if len(sys.argv) > 3 and sys.argv[3] == "wide":                 # wide / tall maps, few channels: grids of other proportions than the model's
+        B = int(rng.integers(1, 4)); C = int(rng.integers(1, 40)); H = int(rng.integers(1, 130)); W = int(rng.integers(20, 420))
     g = torch.Generator(device="cpu").manual_seed(it * 7919 + 13)
     fm0 = (torch.rand(B, C, H, W, generator=g) - 0.5).cuda(); fm1 = (torch.rand(B, C, H, W, generator=g) - 0.5).cuda()
     go = torch.randn(B, H, W, 17, 17, generator=g).cuda()
