@@ -341,10 +341,10 @@ k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, in
             const int j = q < 4 ? 2 * q : 2 * (q - 4) + 1;           // entry q of a pair: j = 0, 2, 4, 6, 1, 3, 5, (7 = pad)
             const unsigned pr = pairs[p];
             const int rl = pr & 255, i = (pr >> 8) & 7, h = pr >> 16;
-            const int jb = j < KT ? colb[rl][j] : 0, n = j < KT ? h * ((jb >> 16) - (jb & 0xffff)) : 0;
+            const int cb = j < KT ? colb[rl][j] : 0, wd = (cb >> 16) - (cb & 0xffff), n = j < KT ? h * wd : 0;
             RmSlot e;
             e.goff = (r0 + rl) * C * KK + i * KT + (j < KT ? j : KT - 1);   // + channel * 49 (the pad points at slot 6: never dereferenced on its own)
-            e.jb = jb;
+            e.jb = n > 0 ? (cb & 0xffff) | (wd << 16) : 0;          // first column | width << 16; a slot that adds nothing (pad, empty bin) has width 0
             e.scale = n > 0 ? 1.0f / static_cast<float>(n) : 0.f;
             e.pad = 0;
             out[nslots + sidx] = e;
@@ -361,8 +361,8 @@ k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, in
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const RmSlot e = out[4 * ks + q];
-            const int j0 = e.jb & 0xffff, j1 = e.jb >> 16;
-            if (e.scale != 0.f && j1 > j0) tm |= ((2 << ((j1 - 1) >> 4)) - 1) & ~((1 << (j0 >> 4)) - 1);   // tiles j0/16 .. (j1-1)/16
+            const int j0 = e.jb & 0xffff, j1 = j0 + (e.jb >> 16);
+            if (j1 > j0) tm |= ((2 << ((j1 - 1) >> 4)) - 1) & ~((1 << (j0 >> 4)) - 1);   // tiles j0/16 .. (j1-1)/16
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[4 * ks + q].pad = tm;
@@ -418,14 +418,20 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
         for (int k0 = 0; k0 < nks; k0 += RG_CH) {
             const int kc = nks - k0 < RG_CH ? nks - k0 : RG_CH;      // k-steps in this chunk
             if (k0) __syncthreads();                                 // previous chunk consumed
-            for (int e = tid; e < 4 * kc; e += NTHR) list[e] = sl[4 * k0 + e];
+            // the chunk's pairs are padded to a multiple of NW x RG_PF with entries that add nothing (width 0, scale 0, tile mask 0) and point
+            // at the last real pair's record: the loops below run without tail guards
+            const int kpp = ((kc >> 1) + NW * RG_PF - 1) / (NW * RG_PF) * (NW * RG_PF);
+            for (int e = tid; e < 8 * kpp; e += NTHR) {
+                RmSlot v = sl[4 * k0 + (e < 4 * kc ? e : 4 * kc - 8 + (e & 7))];
+                if (e >= 4 * kc) { v.jb = 0; v.scale = 0.f; v.pad = 0; }
+                list[e] = v;
+            }
             __syncthreads();
             // wave w takes PAIRS (two k-steps = the 8 entries of one (RoI, bin row)) w, w+NW, ...; lane (n, g) loads the
             // pair's slots 2g, 2g+1 of channel n with one 8-byte load (range-checked: slot "7" of the last record of the
             // tensor lies behind it and reads as 0; its scale is 0 anyway) and multiplies component 0 in the pair's first
             // k-step (entries 8p + g: even slots) and component 1 in its second (entries 8p + 4 + g: odd slots, pad)
-            const int kp = kc >> 1;                                   // pairs in this chunk
-            const int mine = (kp - wave + NW - 1) / NW;
+            const int mine = kpp / NW;                                // this wave's pairs of the padded chunk: a multiple of RG_PF
             f32x2 av[RG_PF][NCT];
             auto a_load = [&](int m, int ct) -> f32x2 {
                 if (dbg & 1) return f32x2{1.f, 1.f};
@@ -435,34 +441,34 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
 #pragma unroll
             for (int q = 0; q < RG_PF; ++q)
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) av[q][ct] = q < mine ? a_load(q, ct) : f32x2{0.f, 0.f};
+                for (int ct = 0; ct < NCT; ++ct) av[q][ct] = a_load(q, ct);
 #pragma unroll 1
             for (int m0 = 0; m0 < mine; m0 += RG_PF) {
+                const bool more = m0 + RG_PF < mine;                 // uniform: the next RG_PF pairs exist (all of them or none)
 #pragma unroll
                 for (int q = 0; q < RG_PF; ++q) {
                     const int m = m0 + q;                            // this wave's m-th pair of the chunk
                     f32x2 cur[NCT];
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) cur[ct] = av[q][ct];
-                    const int nxt = m + RG_PF;                       // refill this register slot
+                    if (more) {                                      // refill this register slot
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) av[q][ct] = nxt < mine ? a_load(nxt, ct) : f32x2{0.f, 0.f};
+                        for (int ct = 0; ct < NCT; ++ct) av[q][ct] = a_load(m + RG_PF, ct);
+                    }
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {                    // the pair's two k-steps
-                        const RmSlot e = list[(dbg & 4) ? g : 8 * (wave + NW * (m < mine ? m : 0)) + 4 * h + g];
-                        const float sc = m < mine ? e.scale : 0.f;
-                        float a[NCT];
+                        const RmSlot e = list[(dbg & 4) ? g : 8 * (wave + NW * m) + 4 * h + g];
+                        // B = 1 / n where the lane's column lies in the slot's bin, else 0 (the scale sits in B: A is gradOut as loaded);
+                        // (unsigned)(col - j0) < width is the whole membership test, false for every column of a slot of width 0
+                        const int d0 = n - (e.jb & 0xffff);
+                        const unsigned wd = (unsigned)e.jb >> 16;
+                        const int tm = __builtin_amdgcn_readfirstlane(e.pad);   // column tiles this k-step reaches
 #pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) a[ct] = sc != 0.f ? cur[ct][h] * sc : 0.f;
-                        const int j0 = sc != 0.f ? e.jb & 0xffff : 0, j1 = sc != 0.f ? e.jb >> 16 : 0;
-                        const int tm = m < mine ? __builtin_amdgcn_readfirstlane(e.pad) : 0;   // column tiles this k-step reaches
-#pragma unroll
-                        for (int x = 0; x < XT; ++x) {               // B: is its column inside the slot's bin?
+                        for (int x = 0; x < XT; ++x) {
                             if (!(tm & (1 << x)) || (dbg & 2)) continue;   // none of the 4 slots reaches this tile: B = 0 (scalar test)
-                            const int col = 16 * x + n;
-                            const float ind = col >= j0 && col < j1 ? 1.f : 0.f;
+                            const float ind = (unsigned)(d0 + 16 * x) < wd ? e.scale : 0.f;
 #pragma unroll
-                            for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], ind, acc[ct][x], 0, 0, 0);
+                            for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[ct][h], ind, acc[ct][x], 0, 0, 0);
                         }
                     }
                 }
@@ -501,7 +507,7 @@ k_roipool_bwd_gemm(const float* __restrict__ gout, const RmSlot* __restrict__ ro
                     float a = 0.f;
                     for (int k = 0; k < 4 * nks; ++k) {
                         const RmSlot sle = sl[k];
-                        if (sle.scale != 0.f && xx >= (sle.jb & 0xffff) && xx < (sle.jb >> 16)) a += gc[sle.goff] * sle.scale;
+                        if ((unsigned)(xx - (sle.jb & 0xffff)) < ((unsigned)sle.jb >> 16)) a += gc[sle.goff] * sle.scale;
                     }
                     gin[((size_t)c * H + y) * W + xx] = a;
                 }
