@@ -271,7 +271,13 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     auto dma = [&](int slot, int chunk, auto k_c) {                  // this wave's k-th DMA instruction of `chunk` into ring slot `slot`
         constexpr int k = decltype(k_c)::value;
         if (k >= nd) return;                                         // wave-uniform
-        const int v = dv[k] == OOR ? OOR : dv[k] + chunk * chunk_bytes;
+        // Chunks are staged in ascending order, each of this wave's instructions once per chunk: its lane offset is ADVANCED by a chunk after
+        // use (parked pieces stay out of range: 0x7ffffff0 + 18 chunks of 153 KB) -- one v_add per DMA instruction, no select.  The f32 MFMA and
+        // the vector ALU do not overlap on a SIMD (csrc/lab/mfma_valu_lab: their times add), so a vector instruction in this loop is matrix time.
+        // (The chunk base in a per-chunk DESCRIPTOR would need none, but hipcc then rebuilds the descriptor behind a waterfall loop.)
+        (void)chunk;
+        const int v = dv[k];
+        dv[k] += chunk_bytes;
         float* dst = smem + slot * SG_BUF + dl[k];
         if (dA[k]) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)dst, 16, v, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, v, 0, 0, 0);
