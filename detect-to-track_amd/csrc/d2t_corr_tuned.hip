@@ -345,12 +345,17 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     struct Frag { f32x4 q[2]; float a[2]; };
     const int dma_pos = (wave >> 2) & 3;                             // D2T_FWD_STAGGER: where in a chunk this wave issues its DMA instructions
     (void)dma_pos;
-    auto run = [&](auto nt_c) {
+    // BPLC: the FM1 image's plane pitch as a compile-time constant (0: the run-time value).  With the pitch in the template the k-step
+    // stride of the fragment reads is an immediate of the ds_read: one address per chunk and fragment instead of one per k-step.  (A vector
+    // instruction is matrix time on this chip -- csrc/lab/mfma_valu_lab.  Unrolling the loop over the three ring slots as well, so that no
+    // address is computed in it at all, ran out of registers: 128 VGPRs + 45 spilled SGPRs.)
+    auto run = [&](auto nt_c, auto bpl_c) {
         constexpr int NT = decltype(nt_c)::value;                    // tasks of this wave: 0, 1 or 2
+        constexpr int BPLC = decltype(bpl_c)::value;
         auto fetch = [&](Frag& f, const float* buf, int ks) {
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
-                f.q[k] = *reinterpret_cast<const f32x4*>(buf + l_off[k] + ks * 4 * BPL);
+                f.q[k] = *reinterpret_cast<const f32x4*>(buf + l_off[k] + ks * 4 * (BPLC ? BPLC : BPL));
                 f.a[k] = buf[a_off[k] + ks * 4 * SG_APL];
             }
         };
@@ -412,9 +417,14 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
         }
     };
     if (wave < SG_WAVES) {                                           // (the loader wave has met the same barriers in its own loop)
-        if (t_on[1]) run(integral_constant<int, 2>{});               // wave-uniform
-        else if (t_on[0]) run(integral_constant<int, 1>{});
-        else run(integral_constant<int, 0>{});
+        // 576 floats: the pitch of every segment of a 38-row map (28 / 26 window rows x 5 column groups, rounded to 16 slots)
+        auto run_nt = [&](auto nt_c) {
+            if (BPL == 576) run(nt_c, integral_constant<int, 576>{});
+            else run(nt_c, integral_constant<int, 0>{});
+        };
+        if (t_on[1]) run_nt(integral_constant<int, 2>{});            // wave-uniform
+        else if (t_on[0]) run_nt(integral_constant<int, 1>{});
+        else run_nt(integral_constant<int, 0>{});
     }
     D2T_STAMP(2);
 #ifdef D2T_LAB
