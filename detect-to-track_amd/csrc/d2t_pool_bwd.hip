@@ -371,9 +371,12 @@ k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, in
 
 constexpr int RG_CH = 128;                    // k-steps (of 4 slots) per LDS chunk of the list: 8 KB
 // lab overrides (make EXTRA=-D...), round 4 at config 3: 8 pairs in flight 67.1 us, 8 waves per task 72.2 us, both 72.5 us against
-// 65.7 us for (4, 4) -- the kernel is bound by the instructions of a k-step (list entry, scale, indicator), not by its loads' latency
+// 65.7 us for (4, 4) -- the kernel is bound by the instructions of a k-step (list entry, scale, indicator), not by its loads' latency.
+// Round 5, with the lean k-step: pairs in flight per wave 1 / 2 / 3 / 4 / 8 -> 57.8 / 59.7 / 62.9 / 61.7 / 67.0 us (R = 300 C = 1891: 106.7 / 109 /
+// 118 / 116 / 126); 8 or 2 waves per task at one pair in flight 61.2 / 76.7 us.  One pair ahead is enough (16 waves per CU hide the rest) and the
+// shortest loop wins: vector and scalar instructions are what the k-step costs beside its MFMAs.
 #ifndef D2T_RG_PF
-#define D2T_RG_PF 4
+#define D2T_RG_PF 1
 #endif
 #ifndef D2T_ROI_NW
 #define D2T_ROI_NW 4
