@@ -1146,20 +1146,19 @@ static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* g
 }
 
 // ---------------------------------------------------------------------------------------
-// PSROIPool backward, ROW form (round 5): the GEMM above without its pair-list and transposing pre-passes.  Three launches (axes,
-// rows, gather) instead of four, no (49, R, 32) copy of gradOut.  Workgroup = task (cell row i, map row y), 7 waves, wave j = bin (i, j):
-//   0. k_ps_axes (R threads) evaluates the 14 bin axes of every RoI once (ps_roipool_cuda.cu:36-54 through the same bin_axis as every
-//      other kernel): rowb[i][r], colb[r][j];
-//   1. all 448 threads scan rowb[i][.] (coalesced) and compact the RoIs whose cell row i contains y into an LDS hit list, ascending;
-//   2. per chunk of 32 hits: 224 threads fetch the hits' column bounds and 1 / n; the hits' gradOut runs gradOut[r][t][i][0..6] -- 28
+// PSROIPool backward, ROW form (round 5): the GEMM above without its pair-list and transposing pre-passes.  TWO launches (rows, gather)
+// instead of four, no (49, R, 32) copy of gradOut.  Workgroup = task (cell row i, map row y), 7 waves, wave j = bin (i, j):
+//   1. all 448 threads evaluate the row bounds of cell row i of the RoIs (ps_roipool_cuda.cu:36-54 through the same bin_axis as every other
+//      kernel; nine RoIs per thread in flight, ONE barrier) and compact the RoIs whose cell row i contains y into an LDS hit list, ascending;
+//   2. per chunk of 32 hits: 224 threads evaluate the hits' column bounds and 1 / n; the hits' gradOut runs gradOut[r][t][i][0..6] -- 28
 //      contiguous bytes per target, so every fetched line serves all seven bins -- go to LDS as A[j][hit][target], two lanes per run
 //      (16 bytes each); the next chunk's loads are issued before this chunk's MFMAs;
 //   3. wave j: D_j[t][x] += A_j[t][hit] * B_j[hit][x] with B = 1 / n inside the cell's columns, 0 outside
 //      (v_mfma_f32_16x16x4_f32: M = targets, N = 16 map columns, K = 4 hits; a column tile no hit of a k-step reaches is skipped).
 // Every plane row is written once as an ascending-RoI chain fma(gradOut, 1 / n, acc): deterministic; <= 1 ulp per term from the
 // reference's gradOut / n (its atomics leave the order open).
-// Measured (bench_ops.py, us; the four-launch GEMM in brackets): R = 300 nT = 21: 26 (31); R = 300 nT = 31: 34 (41); R = 3000 nT = 4: 51
-// (59); R = 3000 nT = 31: 79 (71) -- there the dispatch keeps the GEMM.  Where a task's time goes (tools/kstamps.py,
+// Measured (bench_ops.py, us; the four-launch GEMM in brackets): R = 300 nT = 21: 25 (31); R = 300 nT = 31: 32 (41); R = 3000 nT = 4: 38
+// (59); R = 3000 nT = 31: 87 (71) -- there the dispatch keeps the GEMM.  Where a task's time goes (tools/kstamps.py,
 // profiles/r05_c_kstamps_ps_rows_*.txt, R = 3000 nT = 31, 130 k cycles): the k-steps 59 k (740 cycles each: a cell is ~4 columns wide,
 // an MFMA column tile 16, and 7 waves share 4 matrix pipes), issuing the run loads 37 k (a wave pays ~20 cycles per line its
 // instruction touches, and every (hit, target) run is its own line), the hit list 11 k.  Measured and dropped: the accumulation as an
@@ -1173,29 +1172,12 @@ constexpr int PR_MAXHITS = 4096;                                     // LDS hit 
 constexpr int PR_SCAN = 9;                                           // passes of 448 RoIs per round: 63 (pass, wave) counters, one wave-scan
 static_assert(PR_SCAN * PR_WAVES <= 63 && PR_SCAN * PR_THREADS <= PR_MAXHITS, "hit scan");
 
-// bin axes of every RoI, once: rowb[i][r] = i0 | i1 << 16 of cell row i (coalesced for the scan of a task), colb[r][j] = j0 | j1 << 16
-// of cell column j (32 bytes per RoI).  ps_roipool_cuda.cu:36-54 through the same bin_axis as every other kernel.
-__global__ void __launch_bounds__(256)
-k_ps_axes(const float* __restrict__ rois, int* __restrict__ rowb, int* __restrict__ colb, int R, int H, int W)
-{
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= R) return;
-    const float rI = rois[4 * (size_t)r], rJ = rois[4 * (size_t)r + 1], rH = rois[4 * (size_t)r + 2], rW = rois[4 * (size_t)r + 3];
-#pragma unroll
-    for (int q = 0; q < KT; ++q) {
-        int a0, a1, b0, b1;
-        bin_axis<float>(rI - rH / 2.0f, rH / static_cast<float>(KT), q, H, a0, a1);
-        bin_axis<float>(rJ - rW / 2.0f, rW / static_cast<float>(KT), q, W, b0, b1);
-        rowb[(size_t)q * R + r] = a0 | (a1 << 16);
-        colb[(size_t)r * 8 + q] = b0 | (b1 << 16);
-    }
-    colb[(size_t)r * 8 + 7] = 0;
-}
-
+// The RoIs' row / column bounds are evaluated HERE, by the thread that needs them (one bin_axis per RoI and scan pass, two per staged hit and
+// bin column): a pre-pass that tabulated them per axis (rounds of this file before) cost a launch and a dependency -- 2 us at R = 300, 1 us at
+// R = 3000 (profiles/r05_l_ps_rows_inline_bounds.txt) -- although each of the 266 tasks now repeats the f64 arithmetic of its bin row.
 template <int XT, int NCT>
 __global__ void __launch_bounds__(PR_THREADS)
-k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, const int* __restrict__ rowb, const int* __restrict__ colb,
-              float* __restrict__ part, int R, int nT, int H, int W, int nseg, int rps)
+k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ part, int R, int nT, int H, int W, int nseg, int rps)
 {
     __shared__ int hits[PR_MAXHITS];
     __shared__ int wcnt[64];                                         // hits per (pass, wave) of a round's scan
@@ -1214,7 +1196,6 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, co
     const int y = (p & 1) ? (H - 1) / 2 + d : (H - 1) / 2 - d;
     const int j = wave;                                              // this wave's bin column
     D2T_KSTAMP(0); D2T_KSTAMP_RT(14);
-    const int* rowi = rowb + (size_t)i * R;
     const int bin = i * KT + j;
     f32x4 acc[NCT][XT];
 #pragma unroll
@@ -1237,8 +1218,9 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, co
             const int r = rbase + ps * PR_THREADS + tid;
             bool in = false;
             if (r < rend) {
-                const int rb = rowi[r];
-                in = y >= (rb & 0xffff) && y < (rb >> 16);
+                int a0, a1;                                          // rows of bin row i of RoI r (ps_roipool_cuda.cu:36-54 through bin_axis)
+                bin_axis<float>(rois[4 * (size_t)r] - rois[4 * (size_t)r + 2] / 2.0f, rois[4 * (size_t)r + 2] / static_cast<float>(KT), i, H, a0, a1);
+                in = y >= a0 && y < a1;
             }
             mk[ps] = __ballot(in);
             inb |= in ? 1 << ps : 0;
@@ -1277,7 +1259,10 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, co
                 gjb = 0; gsc = 0.f;
                 if (e0 + e < total) {
                     const int r = hits[e0 + e];
-                    const int rb = rowi[r], cb = colb[(size_t)r * 8 + q];
+                    int a0, a1, b0, b1;
+                    bin_axis<float>(rois[4 * (size_t)r] - rois[4 * (size_t)r + 2] / 2.0f, rois[4 * (size_t)r + 2] / static_cast<float>(KT), i, H, a0, a1);
+                    bin_axis<float>(rois[4 * (size_t)r + 1] - rois[4 * (size_t)r + 3] / 2.0f, rois[4 * (size_t)r + 3] / static_cast<float>(KT), q, W, b0, b1);
+                    const int rb = a0 | (a1 << 16), cb = b0 | (b1 << 16);
                     const int hh = (rb >> 16) - (rb & 0xffff), ww = (cb >> 16) - (cb & 0xffff);
                     gjb = cb;
                     gsc = hh > 0 && ww > 0 ? 1.0f / static_cast<float>(hh * ww) : 0.f;
@@ -1405,23 +1390,19 @@ static int ps_rows_segs(int R, int nT)
     return R >= 1400 && nT <= 16 ? 2 : 1;
 }
 
-// workspace: partial planes (segs, nT*49, H*W) | rowb (7, R) | colb (R, 8)
+// workspace: partial planes (segs, nT*49, H*W)
 static size_t psroipool_bwd_rows_ws_bytes(int R, int nT, int H, int W, int k)
 {
-    return psroipool_bwd_rows_supported(R, nT, H, W, k)
-               ? ps_rows_segs(R, nT) * align256((size_t)nT * KK * H * W * 4) + align256((size_t)KT * R * 4) + align256((size_t)R * 32) : 0;
+    return psroipool_bwd_rows_supported(R, nT, H, W, k) ? ps_rows_segs(R, nT) * align256((size_t)nT * KK * H * W * 4) : 0;
 }
 
 static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, void* ws, hipStream_t st)
 {
     char* w = static_cast<char*>(ws);
     const int nseg = ps_rows_segs(R, nT), rps = (R + nseg - 1) / nseg;
-    float* part = reinterpret_cast<float*>(w); w += nseg * align256((size_t)nT * KK * H * W * 4);
-    int* rowb = reinterpret_cast<int*>(w); w += align256((size_t)KT * R * 4);
-    int* colb = reinterpret_cast<int*>(w);
-    hipLaunchKernelGGL(k_ps_axes, dim3((R + 255) / 256), dim3(256), 0, st, rois, rowb, colb, R, H, W);
+    float* part = reinterpret_cast<float*>(w);
     const int xt = (W + 15) / 16, ntasks = KT * H;
-#define D2T_LAUNCH_PR(XTV, NCTV) hipLaunchKernelGGL((k_ps_bwd_rows<XTV, NCTV>), dim3(ntasks * nseg), dim3(PR_THREADS), 0, st, gout, rois, rowb, colb, part, R, nT, H, W, nseg, rps)
+#define D2T_LAUNCH_PR(XTV, NCTV) hipLaunchKernelGGL((k_ps_bwd_rows<XTV, NCTV>), dim3(ntasks * nseg), dim3(PR_THREADS), 0, st, gout, rois, part, R, nT, H, W, nseg, rps)
 #define D2T_LAUNCH_PR_X(NCTV) { if (xt <= 4) D2T_LAUNCH_PR(4, NCTV); else if (xt <= 5) D2T_LAUNCH_PR(5, NCTV); else D2T_LAUNCH_PR(8, NCTV); }
     if (nT <= 16) D2T_LAUNCH_PR_X(1) else D2T_LAUNCH_PR_X(2)
 #undef D2T_LAUNCH_PR_X
