@@ -297,17 +297,18 @@ constexpr int RM_PS = 8;                                               // list e
 inline int rm_cap(int R) { return R * KT * RM_PS; }
 static size_t rm_lists_bytes(int R, int H) { return align256((size_t)H * rm_cap(R) * sizeof(RmSlot)) + align256((size_t)H * sizeof(int)); }
 
-__global__ void __launch_bounds__(256)
+constexpr int RL_T = 512;                      // threads of a row-list workgroup = RoIs per pass (R = 300: ONE pass; 256 took two, the second with 44 RoIs)
+__global__ void __launch_bounds__(RL_T)
 k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, int* __restrict__ rownks,
                int R, int C, int H, int W, int cap)
 {
-    __shared__ unsigned pairs[256 * KT];                             // RoI - r0 | i << 8 | bin row height << 16
-    __shared__ int colb[256][KT];                                    // j0 | j1 << 16
-    __shared__ int wsum[4];
+    __shared__ unsigned pairs[RL_T * KT];                            // RoI - r0 | i << 10 | bin row height << 16
+    __shared__ int colb[RL_T][KT];                                    // j0 | j1 << 16
+    __shared__ int wsum[RL_T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, y = blockIdx.x;
     RmSlot* out = rowslots + (size_t)y * cap;
     int nslots = 0;                                                  // uniform
-    for (int r0 = 0; r0 < R; r0 += 256) {
+    for (int r0 = 0; r0 < R; r0 += RL_T) {
         __syncthreads();                                             // previous chunk's tables consumed
         int mk = 0, hgt[KT];
         if (r0 + tid < R) {
@@ -330,17 +331,17 @@ k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, in
         __syncthreads();
         int base = 0, npairs = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const int v = wsum[w]; base += w < wave ? v : 0; npairs += v; }
+        for (int w = 0; w < RL_T / 64; ++w) { const int v = wsum[w]; base += w < wave ? v : 0; npairs += v; }
         int pos = base + inc - cnt;
 #pragma unroll
         for (int i = 0; i < KT; ++i)
-            if (mk & (1 << i)) pairs[pos++] = (unsigned)tid | (unsigned)i << 8 | (unsigned)hgt[i] << 16;
+            if (mk & (1 << i)) pairs[pos++] = (unsigned)tid | (unsigned)i << 10 | (unsigned)hgt[i] << 16;
         __syncthreads();
-        for (int sidx = tid; sidx < npairs * RM_PS; sidx += 256) {
+        for (int sidx = tid; sidx < npairs * RM_PS; sidx += RL_T) {
             const int p = sidx / RM_PS, q = sidx - p * RM_PS;
             const int j = q < 4 ? 2 * q : 2 * (q - 4) + 1;           // entry q of a pair: j = 0, 2, 4, 6, 1, 3, 5, (7 = pad)
             const unsigned pr = pairs[p];
-            const int rl = pr & 255, i = (pr >> 8) & 7, h = pr >> 16;
+            const int rl = pr & 1023, i = (pr >> 10) & 7, h = pr >> 16;
             const int cb = j < KT ? colb[rl][j] : 0, wd = (cb >> 16) - (cb & 0xffff), n = j < KT ? h * wd : 0;
             RmSlot e;
             e.goff = (r0 + rl) * C * KK + i * KT + (j < KT ? j : KT - 1);   // + channel * 49 (the pad points at slot 6: never dereferenced on its own)
@@ -356,7 +357,7 @@ k_roi_rowlists(const float* __restrict__ rois, RmSlot* __restrict__ rowslots, in
     __syncthreads();                                                 // the row's list is complete (and visible to this workgroup)
     // per k-step (4 slots): which 16-column tiles does any of its slots reach?  Stored in all four `pad`
     // fields, so that the GEMM kernel skips the other tiles' MFMAs with a scalar test.
-    for (int ks = tid; ks < nks; ks += 256) {
+    for (int ks = tid; ks < nks; ks += RL_T) {
         int tm = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -541,7 +542,7 @@ static int roipool_bwd_mfma_f32(const float* gout, const float* rois, float* gin
     // A is read from gradOut IN PLACE (16 channels of a slot = 16 lines, a 28-byte run of each feeding two
     // k-steps): 83 us at config 3.  Reading an (R, 49, C) copy instead (one line per slot) makes the GEMM kernel
     // 18 us faster but the copy costs 26 us and 60 MB of workspace: 91 us.
-    hipLaunchKernelGGL(k_roi_rowlists, dim3(H), dim3(256), 0, st, rois, rowslots, rownks, R, C, H, W, cap);
+    hipLaunchKernelGGL(k_roi_rowlists, dim3(H), dim3(RL_T), 0, st, rois, rowslots, rownks, R, C, H, W, cap);
     int rc = launch_status();
     if (rc != D2T_OK) return rc;
     const int xt = (W + 15) / 16;
