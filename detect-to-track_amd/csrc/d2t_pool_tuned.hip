@@ -533,10 +533,17 @@ k_ps_roi_order(const float* __restrict__ rois, int* __restrict__ perm, int R, in
         if (key[q] >= 0) perm[pos[q]] = q * 1024 + tid;
 }
 
+// LOCAL: one share and at most PR_T RoIs -- the workgroup orders the RoIs itself (the bucket sort of k_ps_roi_order in LDS: a thread per RoI,
+// ~2 k cycles) instead of reading the order a one-workgroup launch in front of this one wrote: that launch and the dependency on it cost
+// more than 147+ workgroups repeating the sort.  (With several shares the workgroups of a target would have to agree on the order inside
+// a bucket, which the atomics leave open: the pre-pass stays there.)
+template <bool LOCAL>
 __global__ void __launch_bounds__(PR_T)
 k_psroipool_fwd_rows(const float* __restrict__ fm, const float* __restrict__ rois, const int* __restrict__ perm,
                      float* __restrict__ out, int R, int nT, int H, int W, int nshare, int per, int HWp)
 {
+    __shared__ unsigned ohist[LOCAL ? 256 : 1];
+    __shared__ int operm[LOCAL ? PR_T : 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* map = reinterpret_cast<float*>(lds_raw);                  // [7][HWp]
     float* patch = map + KT * HWp;                                   // [waves][64 * 7]
@@ -546,6 +553,33 @@ k_psroipool_fwd_rows(const float* __restrict__ fm, const float* __restrict__ roi
     const int L = blockIdx.x, slot = L >> 3, g = (slot / KT) * 8 + (L & 7), i = slot % KT;
     if (g >= nT * nshare) return;
     const int t = g / nshare, share = g - t * nshare;
+    if (LOCAL) {                                                     // the order of k_ps_roi_order, for R <= PR_T, into LDS
+        if (tid < 256) ohist[tid] = 0;
+        const float4 roi = tid < R ? reinterpret_cast<const float4*>(rois)[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        float fh = roi.z * (float)H * (1.f / KT), fw = roi.w * (float)W * (1.f / KT);
+        fh = fh == fh ? fh : 0.f; fw = fw == fw ? fw : 0.f;
+        const int bh = (int)fminf(fmaxf(fh, 0.f), 14.f) + 1, bw = (int)fminf(fmaxf(fw, 0.f), 14.f) + 1;
+        const int key = tid < R ? bh * 16 + bw : -1;
+        if (key >= 0) atomicAdd(&ohist[key], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            unsigned c[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[k] = ohist[4 * tid + k]; sum += c[k]; }
+            unsigned incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned tt = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += tt;
+            }
+            unsigned run = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ohist[4 * tid + k] = run; run += c[k]; }
+        }
+        __syncthreads();
+        if (key >= 0) operm[atomicAdd(&ohist[key], 1u)] = tid;       // (order inside a bucket: arbitrary -- this workgroup takes every RoI)
+    }
     for (int e0 = 0; e0 < HW; e0 += PR_T * PR_Q) {                   // (one round at 38 x 75)
         float v[KT][PR_Q];
 #pragma unroll
@@ -573,7 +607,7 @@ k_psroipool_fwd_rows(const float* __restrict__ fm, const float* __restrict__ roi
         const int k = k0 + tid;
         if (k0 + (wave << 6) >= k_end) break;                        // wave-uniform; nothing below synchronises the workgroup
         const bool live = k < k_end;
-        const int r = live ? perm[k] : -1;
+        const int r = live ? (LOCAL ? operm[k] : perm[k]) : -1;
         int i0 = 0, i1 = 0, x0[KT], w[KT], wmax = 0;
 #pragma unroll
         for (int j = 0; j < KT; ++j) { x0[j] = 0; w[j] = 0; }
@@ -676,11 +710,17 @@ int psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int
     if (ps_fwd_small(R, nT)) return psroipool_fwd_small_f32(fm, rois, out, R, nT, H, W, k, st);
     if (ps_rows_fit(R, nT, H, W)) {
         int* perm = static_cast<int*>(ws);
-        hipLaunchKernelGGL(k_ps_roi_order, dim3(1), dim3(1024), 0, st, rois, perm, R, H, W);
         int nshare, per;
         ps_rows_shares(R, nT, nshare, per);
-        D2T_ENSURE_DYNAMIC_LDS(k_psroipool_fwd_rows, LDS_MAX);
-        hipLaunchKernelGGL(k_psroipool_fwd_rows, dim3((nT * nshare + 7) / 8 * 8 * KT), dim3(PR_T), ps_rows_lds(H, W), st,
+        if (nshare == 1 && R <= PR_T && ps_rows_lds(H, W) <= (size_t)LDS_MAX - 8192 && !lab_env_int("D2T_PS_FWD_PREPASS", 0)) {   // one launch: every workgroup orders the RoIs itself
+            D2T_ENSURE_DYNAMIC_LDS(k_psroipool_fwd_rows<true>, LDS_MAX - 8192);          // 5 KB of static LDS (histogram, order) beside the maps
+            hipLaunchKernelGGL(k_psroipool_fwd_rows<true>, dim3((nT * nshare + 7) / 8 * 8 * KT), dim3(PR_T), ps_rows_lds(H, W), st,
+                               fm, rois, perm, out, R, nT, H, W, nshare, per, (H * W + 3) & ~3);
+            return launch_status();
+        }
+        hipLaunchKernelGGL(k_ps_roi_order, dim3(1), dim3(1024), 0, st, rois, perm, R, H, W);
+        D2T_ENSURE_DYNAMIC_LDS(k_psroipool_fwd_rows<false>, LDS_MAX);
+        hipLaunchKernelGGL(k_psroipool_fwd_rows<false>, dim3((nT * nshare + 7) / 8 * 8 * KT), dim3(PR_T), ps_rows_lds(H, W), st,
                            fm, rois, perm, out, R, nT, H, W, nshare, per, (H * W + 3) & ~3);
         return launch_status();
     }
