@@ -1265,8 +1265,11 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
                     bin_axis<float>(rois[4 * (size_t)r + 1] - rois[4 * (size_t)r + 3] / 2.0f, rois[4 * (size_t)r + 3] / static_cast<float>(KT), q, W, b0, b1);
                     const int rb = a0 | (a1 << 16), cb = b0 | (b1 << 16);
                     const int hh = (rb >> 16) - (rb & 0xffff), ww = (cb >> 16) - (cb & 0xffff);
-                    gjb = cb;
-                    gsc = hh > 0 && ww > 0 ? 1.0f / static_cast<float>(hh * ww) : 0.f;
+                    // first column | width << 8 | column-tile mask << 16; a cell that adds nothing (no rows, no columns) has width 0 and no tiles
+                    const int j0c = cb & 0xffff, j1c = cb >> 16;
+                    const bool any = hh > 0 && ww > 0;
+                    gjb = any ? j0c | (ww << 8) | ((((2 << ((j1c - 1) >> 4)) - 1) & ~((1 << (j0c >> 4)) - 1)) << 16) : 0;
+                    gsc = any ? 1.0f / static_cast<float>(hh * ww) : 0.f;
                 }
             }
 #pragma unroll
@@ -1313,23 +1316,30 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) o.a[ct] = A[buf][j][e][16 * ct + n];
             };
-            KOp cur, nxt;
-            kfetch(cur, 0);
-            for (int ks = 0; ks < nks; ++ks) {
-                if (ks + 1 < nks) kfetch(nxt, ks + 1); else nxt = cur;
-                const int j0 = cur.jb & 0xffff, j1 = cur.jb >> 16;
-                const int tb2 = cur.sc != 0.f && j1 > j0 ? ((2 << ((j1 - 1) >> 4)) - 1) & ~((1 << (j0 >> 4)) - 1) : 0;
-                const int tm2 = __builtin_amdgcn_readlane(tb2, 0) | __builtin_amdgcn_readlane(tb2, 16) | __builtin_amdgcn_readlane(tb2, 32) |
-                                __builtin_amdgcn_readlane(tb2, 48);
+            // one k-step: the lane's membership test is (unsigned)(column - first column) < width (false for every column of a width-0 entry),
+            // the scale sits in the B operand; the tile mask of the k-step is the OR of its four entries' masks, read across the lane groups
+            // as scalars -- no vector instruction.  (Vector instructions are matrix time here: csrc/lab/mfma_valu_lab.)
+            auto kstep = [&](const KOp& o) {
+                const int d0 = n - (o.jb & 0xff);
+                const unsigned wd = ((unsigned)o.jb >> 8) & 0xffu;
+                const int tm2 = (__builtin_amdgcn_readlane(o.jb, 0) | __builtin_amdgcn_readlane(o.jb, 16) | __builtin_amdgcn_readlane(o.jb, 32) |
+                                 __builtin_amdgcn_readlane(o.jb, 48)) >> 16;
 #pragma unroll
                 for (int x = 0; x < XT; ++x) {
                     if (!(tm2 & (1 << x))) continue;                 // no hit of this k-step reaches the column tile (scalar test)
-                    const int col = 16 * x + n;
-                    const float b = col >= j0 && col < j1 ? cur.sc : 0.f;
+                    const float b = (unsigned)(d0 + 16 * x) < wd ? o.sc : 0.f;
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[ct], b, acc[ct][x], 0, 0, 0);
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[ct], b, acc[ct][x], 0, 0, 0);
                 }
-                cur = nxt;
+            };
+            KOp ka, kb;                                              // two entries that swap roles: no register moves between k-steps
+            kfetch(ka, 0);
+            for (int ks = 0; ks < nks; ks += 2) {
+                if (ks + 1 < nks) kfetch(kb, ks + 1);
+                kstep(ka);
+                if (ks + 1 >= nks) break;
+                if (ks + 2 < nks) kfetch(ka, ks + 2);
+                kstep(kb);
             }
             D2T_KCLK(k2);
             if (c + 1 < nchunk) store_chunk(buf ^ 1);
