@@ -1150,7 +1150,7 @@ static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* g
 // PSROIPool backward, ROW form (round 5): the GEMM above without its pair-list and transposing pre-passes.  TWO launches (rows, gather)
 // instead of four, no (49, R, 32) copy of gradOut.  Workgroup = task (cell row i, map row y), 7 waves, wave j = bin (i, j):
 //   1. all 448 threads evaluate the row bounds of cell row i of the RoIs (ps_roipool_cuda.cu:36-54 through the same bin_axis as every other
-//      kernel; nine RoIs per thread in flight, ONE barrier) and compact the RoIs whose cell row i contains y into an LDS hit list, ascending;
+//      kernel; four RoIs per thread in flight, ONE barrier) and compact the RoIs whose cell row i contains y into an LDS hit list, ascending;
 //   2. per chunk of 32 hits: 224 threads evaluate the hits' column bounds and 1 / n; the hits' gradOut runs gradOut[r][t][i][0..6] -- 28
 //      contiguous bytes per target, so every fetched line serves all seven bins -- go to LDS as A[j][hit][target], two lanes per run
 //      (16 bytes each); the next chunk's loads are issued before this chunk's MFMAs;
@@ -1167,10 +1167,11 @@ static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* g
 // 158 us (profiles/r05_c_kstamps_ps_rows_lds_rmw_lost.txt).
 // ---------------------------------------------------------------------------------------
 constexpr int PR_WAVES = KT, PR_THREADS = PR_WAVES * 64;             // 448
-constexpr int PR_EC = 32;                                            // hits per chunk = 8 k-steps
+constexpr int PR_EC = 32;                                            // hits per chunk with two c-tiles per wave (one c-tile: 64)
 constexpr int PR_TP = 32;                                            // targets padded to two c-tiles
-constexpr int PR_MAXHITS = 4096;                                     // LDS hit list (ints); more hits: further rounds
-constexpr int PR_SCAN = 9;                                           // passes of 448 RoIs per round: 63 (pass, wave) counters, one wave-scan
+constexpr int PR_MAXHITS = 2048;                                     // LDS hit list (ints); more RoIs in a workgroup's range: further rounds
+constexpr int PR_SCAN = 4;                                           // passes of 448 RoIs per round (1,792): 28 (pass, wave) counters, one wave-scan;
+                                                                     // (two workgroups per CU need the kernel's static LDS below 80 KB)
 static_assert(PR_SCAN * PR_WAVES <= 63 && PR_SCAN * PR_THREADS <= PR_MAXHITS, "hit scan");
 
 // The RoIs' row / column bounds are evaluated HERE, by the thread that needs them (one bin_axis per RoI and scan pass, two per staged hit and
@@ -1182,9 +1183,12 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
 {
     __shared__ int hits[PR_MAXHITS];
     __shared__ int wcnt[64];                                         // hits per (pass, wave) of a round's scan
-    __shared__ __attribute__((aligned(16))) float A[2][KT][PR_EC][PR_TP];   // 2 x 28 KB
-    __shared__ int ejb[2][PR_EC][KT + 1];
-    __shared__ float esc[2][PR_EC][KT + 1];
+    // a chunk holds EC hits x TP targets: 32 x 32 with two c-tiles per wave, 64 x 16 with one (up to 16 targets) -- the same 28 KB per buffer,
+    // half the chunk barriers where thousands of RoIs make a task walk many chunks
+    constexpr int EC = NCT == 1 ? 2 * PR_EC : PR_EC, TP = NCT == 1 ? PR_TP / 2 : PR_TP;
+    __shared__ __attribute__((aligned(16))) float A[2][KT][EC][TP];  // 2 x 28 KB
+    __shared__ int ejb[2][EC][KT + 1];
+    __shared__ float esc[2][EC][KT + 1];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // one task per workgroup, numbered from the middle rows outwards: they carry the most hits and start first
@@ -1206,10 +1210,10 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
     const unsigned gout_bytes = (unsigned)((size_t)R * nT * KK * 4);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, gout_bytes, 0x00020000);
 
-    for (int rbase = r_lo; rbase < r_hi; rbase += PR_SCAN * PR_THREADS) {   // one round unless more than 4032 RoIs in the range
+    for (int rbase = r_lo; rbase < r_hi; rbase += PR_SCAN * PR_THREADS) {   // one round unless more than 1,792 RoIs in the range
         const int rend = r_hi - rbase < PR_SCAN * PR_THREADS ? r_hi : rbase + PR_SCAN * PR_THREADS;
-        // ---- 1. hit list of RoIs [rbase, rend): ascending.  Thread tid tests RoIs rbase + 448 p + tid, p < 9, with all its loads in
-        // flight together; the 9 x 7 (pass, wave) counts meet at ONE barrier and every wave scans the 63 of them by itself.  (A barrier
+        // ---- 1. hit list of RoIs [rbase, rend): ascending.  Thread tid tests RoIs rbase + 448 p + tid, p < 4, with all its loads in
+        // flight together; the 4 x 7 (pass, wave) counts meet at ONE barrier and every wave scans the 28 of them by itself.  (A barrier
         // pair per pass of 448 RoIs, as at first, was 1.6 k cycles per pass: 11 k cycles for 3000 RoIs.)
         if (rbase != r_lo) __syncthreads();                          // the previous round's counts and hits have been consumed
         unsigned long long mk[PR_SCAN];
@@ -1245,17 +1249,17 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
         __syncthreads();
         D2T_KSTAMP(1);
         // ---- 2 + 3. chunks of 32 hits
-        const int nchunk = (total + PR_EC - 1) / PR_EC;
+        const int nchunk = (total + EC - 1) / EC;
         // What a thread stages per chunk.  (hit e, bin column q) for tid < 224: column bounds and 1 / n from the axis tables.  The
         // runs gradOut[r][t][i][0..6] -- 28 contiguous bytes -- by TWO lanes each (bytes 0..15 and 12..27, one 16-byte load per lane):
         // a vector-memory instruction costs its wave ~15-20 cycles per line it touches, and this way 64 lanes touch 32 lines once
         // (seven dword loads per run touched every line seven times: 20 k cycles per chunk).
-        constexpr int NLD = (2 * PR_EC * PR_TP + PR_THREADS - 1) / PR_THREADS;   // 5
+        constexpr int NLD = (2 * EC * TP + PR_THREADS - 1) / PR_THREADS;   // 5
         f32x4 run[NLD];
         int gjb = 0; float gsc = 0.f;
         auto load_chunk = [&](int c) {                               // global -> registers
-            const int e0 = c * PR_EC;
-            if (tid < PR_EC * KT) {
+            const int e0 = c * EC;
+            if (tid < EC * KT) {
                 const int e = tid / KT, q = tid - e * KT;
                 gjb = 0; gsc = 0.f;
                 if (e0 + e < total) {
@@ -1274,21 +1278,21 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
             }
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
-                const int sl = tid + k * PR_THREADS, rn = sl >> 1, half = sl & 1, e = rn / PR_TP, t = rn - e * PR_TP;
-                const bool on = rn < PR_EC * PR_TP && e0 + e < total && t < nT;
+                const int sl = tid + k * PR_THREADS, rn = sl >> 1, half = sl & 1, e = rn / TP, t = rn - e * TP;
+                const bool on = rn < EC * TP && e0 + e < total && t < nT;
                 const int off = on ? ((hits[e0 + (on ? e : 0)] * nT + t) * KK + i * KT) * 4 + 12 * half : 0x7ffffff0;   // out of range: zeros
                 run[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
             }
         };
         auto store_chunk = [&](int buf) {                            // registers -> LDS
-            if (tid < PR_EC * KT) {
+            if (tid < EC * KT) {
                 const int e = tid / KT, q = tid - e * KT;
                 ejb[buf][e][q] = gjb; esc[buf][e][q] = gsc;
             }
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
-                const int sl = tid + k * PR_THREADS, rn = sl >> 1, half = sl & 1, e = rn / PR_TP, t = rn - e * PR_TP;
-                if (rn < PR_EC * PR_TP) {
+                const int sl = tid + k * PR_THREADS, rn = sl >> 1, half = sl & 1, e = rn / TP, t = rn - e * TP;
+                if (rn < EC * TP) {
                     if (half == 0) { A[buf][0][e][t] = run[k][0]; A[buf][1][e][t] = run[k][1]; A[buf][2][e][t] = run[k][2]; A[buf][3][e][t] = run[k][3]; }
                     else { A[buf][4][e][t] = run[k][1]; A[buf][5][e][t] = run[k][2]; A[buf][6][e][t] = run[k][3]; }
                 }
@@ -1303,7 +1307,7 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
             D2T_KCLK(k0);
             if (c + 1 < nchunk) load_chunk(c + 1);                   // in flight under the MFMAs
             D2T_KCLK(k1);
-            const int ne = total - c * PR_EC < PR_EC ? total - c * PR_EC : PR_EC;
+            const int ne = total - c * EC < EC ? total - c * EC : EC;
             const int nks = (ne + 3) >> 2;                           // uniform
             // k-steps, software-pipelined: the entry (column bounds, 1 / n, the A values of this lane's targets) of k-step ks+1 is read
             // from LDS before the MFMAs of ks; which column tiles a k-step reaches is ONE scalar mask -- the OR of its four hits' tile

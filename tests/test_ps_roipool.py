@@ -217,7 +217,7 @@ def test_nonfinite_gradout_gemm_backward(case):
 @pytest.mark.parametrize("case", [(1500, 4, 38, 75), (3000, 16, 38, 63), (1401, 7, 19, 40), (4500, 2, 38, 75)], ids=str)
 def test_row_form_backward_roi_ranges(case, oracle):
     """The row-form backward (k_ps_bwd_rows, round 5) deals a task's RoIs to TWO workgroups from 1,400 RoIs up (<= 16 targets) and the
-    gather adds the partial planes; 4,500 RoIs also take a second round of the hit scan (4,032 RoIs per round).  Signed data against the
+    gather adds the partial planes; 4,500 RoIs in two ranges also take a second round of the hit scan (1,792 RoIs per round).  Signed data against the
     yardstick with the reference's f32 terms added in double (ps_roipool_cuda.cu:120-139): 1e-5 of the sum of |terms|; Inf / NaN in
     gradOut: the pattern and the finite values of the reference-order kernels; deterministic."""
     from detect_to_track.models import _ext
