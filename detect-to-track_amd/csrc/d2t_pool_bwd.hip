@@ -1039,20 +1039,20 @@ k_ps_bwd_gemm(const float* __restrict__ vt, const PgPair* __restrict__ lists, co
 #pragma unroll
             for (int q = 0; q < RG_PF; ++q) {
                 const RmSlot e = my[4 * NW * (m0 + q)];
-                float a[NCT];
+                float a[NCT];                                        // A = gradOut as loaded; the scale sits in B (vector instructions are matrix time)
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) a[ct] = e.scale != 0.f ? av[q][ct] * e.scale : 0.f;
+                for (int ct = 0; ct < NCT; ++ct) a[ct] = av[q][ct];
                 const int nxt = m0 + q + RG_PF < mine ? m0 + q + RG_PF : mine - 1;
                 const int go = my[4 * NW * nxt].goff;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) av[q][ct] = va[go + 16 * ct];
-                const int j0 = e.jb & 0xffff, j1 = e.jb >> 16;
+                const int d0 = n - (e.jb & 0xffff);
+                const unsigned wd = (unsigned)((e.jb >> 16) - (e.jb & 0xffff));   // (a slot with scale 0 multiplies by B = 0 whatever its range)
                 const int tm = __builtin_amdgcn_readfirstlane(e.pad);
 #pragma unroll
                 for (int x = 0; x < XT; ++x) {
                     if (!(tm & (1 << x))) continue;
-                    const int col = 16 * x + n;
-                    const float ind = col >= j0 && col < j1 ? 1.f : 0.f;
+                    const float ind = (unsigned)(d0 + 16 * x) < wd ? e.scale : 0.f;
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) acc[ct][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], ind, acc[ct][x], 0, 0, 0);
                 }
