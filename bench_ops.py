@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--full", type=int, default=1, help="1: also the metric shape, the small PSROIPool shapes and the tracker glue")
     ap.add_argument("--pmc-markers", default=None, help="tools/ops_pmc.sh: write (label, calls) of every timed series to this JSON-lines file and "
-                    "launch a marker kernel (k_corr_mask) in front of each, so that a rocprofv3 --pmc pass can be cut into the series")
+                    "launch a marker (two 1 x 1 k_corr_mask dispatches) in front of each, so that a rocprofv3 --pmc pass can be cut into the series")
     args = ap.parse_args()
     if args.pmc_markers:
         global MARKER
@@ -248,7 +248,8 @@ def main():
         def MARKER(label, calls):
             fh.write(json.dumps({"label": label, "calls": calls}) + "\n")
             fh.flush()
-            _check(L.d2t_corr_mask(mk.data_ptr(), 1, 1, 0, 1, torch.cuda.current_stream().cuda_stream))
+            for _ in range(2):                                      # the marker is a PAIR of 1 x 1 masks (tools/ops_pmc_reduce.py): no series launches that
+                _check(L.d2t_corr_mask(mk.data_ptr(), 1, 1, 0, 1, torch.cuda.current_stream().cuda_stream))
     for e in measure("cuda:0", args.impl, args.iters, bool(args.full)):
         print(json.dumps(e), flush=True)
 

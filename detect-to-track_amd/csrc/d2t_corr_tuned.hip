@@ -184,7 +184,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     // and those cells are masked in the epilogue.  Pad slots and pixel rows past the map are parked
     // out of range.  Instruction y of a chunk (FM1 instructions first, then the 5 FM0 ones) belongs to
     // wave y mod 15.
-    constexpr int OOR = 0x7ffffff0;                                  // parked byte offset: always out of range
+    constexpr unsigned OOR = 0x7ffffff0u;                            // parked byte offset: always out of range
     const int P = (nrows * NCG + 15) & ~15;                          // slots per channel
     const int BPL = 4 * P;                                           // floats per channel plane
     const int a_base = SG_KC * BPL;                                  // float offset of the FM0 part in a buffer
@@ -213,7 +213,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
                 const int e = k * 64 + lane;
                 const int ch = (int)(((float)e + 0.5f) * rP), rem = e - ch * P;   // e / P, exact for e < 2^15
                 const int row = rem / NCG, cg = rem - row * NCG;
-                const int vo = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 + cb : OOR;
+                const int vo = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 + cb : (int)OOR;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(buf + k * 256), 16, vo, 0, 0, 0);
             }
 #pragma unroll
@@ -221,7 +221,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
                 const int e = k * 64 + lane;
                 const int ch = e / (4 * SG_NU), prow = e - ch * (4 * SG_NU);
                 const int i = 4 * u0 + prow;
-                const int vo = i < H ? (ch * HW + i * W + j0) * 4 + cb : OOR;
+                const int vo = i < H ? (ch * HW + i * W + j0) * 4 + cb : (int)OOR;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)(buf + a_base + k * 256), 16, vo, 0, 0, 0);
             }
         };
@@ -248,7 +248,11 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     auto wait_prev_chunk_and_barrier = [&]() { lds_barrier(); };
 #else
     const int nd = (ndma - wave + SG_WAVES - 1) / SG_WAVES;          // this wave's instructions per chunk (wave-uniform)
-    int dv[SG_MAXDMA], dl[SG_MAXDMA];                                // byte offset in the planes / float offset in the buffer
+    // dv is UNSIGNED: a parked piece starts at OOR and is advanced by a chunk like every other piece; corr_fwd_supported() bounds
+    // (C + 8 * SG_KC) * H * W * 4 below 0x7ffffff0, so OOR + (nchunks + 2) * chunk_bytes stays below 2^32 (no wrap back into the
+    // planes) and above plane_bytes (still rejected by the range check) for every shape admitted -- C = 2048 has 130 chunks.
+    unsigned dv[SG_MAXDMA];                                          // byte offset in the planes
+    int dl[SG_MAXDMA];                                               // float offset in the buffer
     bool dA[SG_MAXDMA];
 #pragma unroll
     for (int k = 0; k < SG_MAXDMA; ++k) {
@@ -258,13 +262,13 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
             const int e = y * 64 + lane;
             const int ch = (int)(((float)e + 0.5f) * rP), rem = e - ch * P;   // e / P, exact for e < 2^15
             const int row = rem / NCG, cg = rem - row * NCG;
-            dv[k] = row < nrows ? (ch * HW + (R0 + row) * W + colL + 4 * cg) * 4 : OOR;
+            dv[k] = row < nrows ? (unsigned)((ch * HW + (R0 + row) * W + colL + 4 * cg) * 4) : OOR;
             dl[k] = y * 256;
         } else {
             const int e = (y - nBI) * 64 + lane;                     // FM0 piece: (channel, pixel row of the segment)
             const int ch = e / (4 * SG_NU), prow = e - ch * (4 * SG_NU);
             const int i = 4 * u0 + prow;
-            dv[k] = i < H ? (ch * HW + i * W + j0) * 4 : OOR;
+            dv[k] = i < H ? (unsigned)((ch * HW + i * W + j0) * 4) : OOR;
             dl[k] = a_base + (y - nBI) * 256;
         }
     }
@@ -272,12 +276,12 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
         constexpr int k = decltype(k_c)::value;
         if (k >= nd) return;                                         // wave-uniform
         // Chunks are staged in ascending order, each of this wave's instructions once per chunk: its lane offset is ADVANCED by a chunk after
-        // use (parked pieces stay out of range: 0x7ffffff0 + 18 chunks of 153 KB) -- one v_add per DMA instruction, no select.  The f32 MFMA and
+        // use (parked pieces stay out of range, see dv above) -- one v_add per DMA instruction, no select.  The f32 MFMA and
         // the vector ALU do not overlap on a SIMD (csrc/lab/mfma_valu_lab: their times add), so a vector instruction in this loop is matrix time.
         // (The chunk base in a per-chunk DESCRIPTOR would need none, but hipcc then rebuilds the descriptor behind a waterfall loop.)
         (void)chunk;
-        const int v = dv[k];
-        dv[k] += chunk_bytes;
+        const int v = (int)dv[k];                                    // the instruction's voffset is unsigned in hardware
+        dv[k] += (unsigned)chunk_bytes;
         float* dst = smem + slot * SG_BUF + dl[k];
         if (dA[k]) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (lds_ptr)dst, 16, v, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, v, 0, 0, 0);

@@ -697,9 +697,20 @@ bool psroipool_fwd_supported(int R, int nT, int H, int W, int k)
            (R + PF_RC - 1) / PF_RC <= 65535 && 1LL * nT * KK * R < 0x7fffffffLL && (nT * KK + 255) / 256 <= 65535;
 }
 
+// The bin-row form as ONE launch (every workgroup orders the RoIs itself, in LDS): a target is one share of at most PR_T RoIs and
+// the maps leave 8 KB for the histogram / order arrays.  Needs NO workspace.  One predicate for the workspace query and the launcher.
+static bool ps_rows_local_order(int R, int nT, int H, int W)
+{
+    if (!ps_rows_fit(R, nT, H, W)) return false;
+    int nshare, per;
+    ps_rows_shares(R, nT, nshare, per);
+    return nshare == 1 && R <= PR_T && ps_rows_lds(H, W) <= (size_t)LDS_MAX - 8192;
+}
+
 size_t psroipool_fwd_ws_bytes(int R, int nT, int H, int W, int k)
 {
     if (!psroipool_fwd_supported(R, nT, H, W, k) || ps_fwd_small(R, nT)) return 0;
+    if (ps_rows_local_order(R, nT, H, W)) return 0;
     if (ps_rows_fit(R, nT, H, W)) return align256((size_t)R * sizeof(int));
     return cellsT_bytes(R) + align256((size_t)nT * KK * R * sizeof(float));
 }
@@ -712,7 +723,7 @@ int psroipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int
         int* perm = static_cast<int*>(ws);
         int nshare, per;
         ps_rows_shares(R, nT, nshare, per);
-        if (nshare == 1 && R <= PR_T && ps_rows_lds(H, W) <= (size_t)LDS_MAX - 8192 && !lab_env_int("D2T_PS_FWD_PREPASS", 0)) {   // one launch: every workgroup orders the RoIs itself
+        if (ps_rows_local_order(R, nT, H, W)) {                      // one launch: every workgroup orders the RoIs itself (perm unused: no workspace)
             D2T_ENSURE_DYNAMIC_LDS(k_psroipool_fwd_rows<true>, LDS_MAX - 8192);          // 5 KB of static LDS (histogram, order) beside the maps
             hipLaunchKernelGGL(k_psroipool_fwd_rows<true>, dim3((nT * nshare + 7) / 8 * 8 * KT), dim3(PR_T), ps_rows_lds(H, W), st,
                                fm, rois, perm, out, R, nT, H, W, nshare, per, (H * W + 3) & ~3);

@@ -44,6 +44,13 @@ def _check_corr_envelope(x: Tensor, d_max: int, stride: int, impl: int) -> None:
                           "about 2x (forward) / 2.7x (backward) slower")
 
 
+def _check_corr_bwd_envelope(x: Tensor, d_max: int, stride: int, impl: int) -> None:
+    """The backward's envelope is narrower than the forward's: the 8-wave strip kernel walks super-steps of 4 map rows with five tiles
+    alive and needs H >= 17 (csrc/d2t_corr_bwd8.hip: corr_bwd8_supported, tiles_i >= 5; include/d2t_ops.h, D2T_IMPL_MFMA)."""
+    if x.dtype == torch.float32 and impl == _native.IMPL_AUTO and x.numel() and d_max == 8 and stride == 1 and x.shape[-1] >= 20 and x.shape[-2] < 17:
+        _outside_envelope("PointwiseCorrelation backward", f"H = {x.shape[-2]} (tuned backward: H >= 17)", "about 2.7x slower")
+
+
 def _check_pool_envelope(kind: str, x: Tensor, k: int, impl: int) -> None:
     if x.dtype == torch.float32 and impl == _native.IMPL_AUTO and x.numel() and k != 7:
         if kind == "ROIPool":
@@ -137,6 +144,7 @@ def pointwise_correlation_backward(grad_out: Tensor, FM0: Tensor, FM1: Tensor, d
         raise RuntimeError(
             f"shape mismatch: FM0 {tuple(FM0.shape)}, FM1 {tuple(FM1.shape)}, gradOut {tuple(grad_out.shape)} "
             f"(expected gradOut {(B, H, W, cw, cw)})")
+    _check_corr_bwd_envelope(FM0, d_max, stride, impl)
     with torch.cuda.device(FM0.device):
         g0 = torch.empty_like(FM0)
         g1 = torch.empty_like(FM1)

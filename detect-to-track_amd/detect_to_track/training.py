@@ -17,8 +17,11 @@ What of the reference is mirrored here, and where it differs:
   masked smooth-L1) are out of scope: targets come from the manager and the terms are plain
   NLL / smooth-L1 of the same shapes -- parity for this row is about shapes, call pattern and the ops inside.
 * ``DataParallelTrainer.train_step`` follows ``_minibatch_loss`` + ``train`` (``trainer.py:258-281``): losses summed over
-  the minibatch's pairs, ONE backward with the loss coefficients, one optimizer step -- plus, between the two, the
-  bucketed gradient all-reduce of ``data_parallel.GradientBuckets`` when there is more than one rank.
+  the minibatch's pairs, ONE backward of ``dot(coefs, losses) / pairs`` (``DTLoss.to_scalar``, ``utils.py:64-75``: the
+  scalar is normalised by the pair count), one optimizer step -- plus, between the two, the bucketed gradient all-reduce
+  of ``data_parallel.GradientBuckets`` when there is more than one rank.  Because every rank normalises by ITS pair
+  count, the mean over ranks with equal shards IS the single-process gradient over all pairs (SURVEY §8e;
+  tests/test_data_parallel_equivalence.py checks that on the GPU with the real model).
 """
 from collections import OrderedDict
 from typing import Callable, Iterator, List, NamedTuple, Optional, Sequence, Tuple
@@ -213,7 +216,7 @@ class DataParallelTrainer:
 
     def train_step(self, minibatch: Sequence[PairInstance], mark: Optional[Callable[[], object]] = None):
         """trainer.py:258-281 for one minibatch.  Returns (summed losses, per-pair section stamps, (b0, b1, b2) marks
-        around backward + all-reduce and the optimizer step)."""
+        around backward + all-reduce and the optimizer step).  The gradient is that of the MEAN over the minibatch's pairs."""
         total = torch.zeros(5, device=self.coefs.device)
         stamps = []
         if self.batched:
@@ -229,7 +232,7 @@ class DataParallelTrainer:
         else:
             self.optim.zero_grad(set_to_none=True)
         b0 = mark() if mark else None
-        total.backward(self.coefs)                                                # :275
+        total.backward(self.coefs / float(len(minibatch)))                        # :275 -> DTLoss.to_scalar: dot(coefs, losses) / count (utils.py:64-75)
         if self.buckets is not None:
             self.buckets.wait()                                                   # the all-reduces ran under the backward pass
         b1 = mark() if mark else None

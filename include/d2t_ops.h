@@ -92,7 +92,8 @@ const char* d2t_error_string(int code);
  *                    (ROIPool forward with fewer than 32 RoIs takes the generic kernel), else generic
  *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)
  *   D2T_IMPL_MFMA    the tuned path, demanded: correlation returns D2T_EINVAL when its preconditions
- *                    (d_max = 8, stride 1, W >= 20) do not hold; the pooling ops fall back to generic */
+ *                    (d_max = 8, stride 1, W >= 20; backward: H >= 17 as well -- the strip kernel keeps five
+ *                    4-row tiles alive) do not hold; the pooling ops fall back to generic */
 enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_FAST = 5 };
 /*   D2T_IMPL_FAST    as D2T_IMPL_AUTO, and the correlation FORWARD may re-associate its channel sum: small grids with
  *                    many channels (the model's B = 1 pairs with 1024 / 2048 channels) split the channels of a level

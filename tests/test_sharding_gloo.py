@@ -117,6 +117,14 @@ def test_bench_rank_skeleton_under_torchrun():
         ta = k["roofline_ta"]
         assert ta is None or (ta["lines"] > 0 and ta["peak"] > 0 and abs(ta["frac"] - ta["achieved"] / ta["peak"]) < 1e-9)
     assert d["ops"] is None and d["process_group"] == "gloo"
+    # round-6 fields: where `traffic` came from (never this run: PMC needs rocprofv3 around the process), the launch duration with the
+    # event record taken out beside the raw interval, and the forward -- the kernel the metric string names -- against both roofs
+    r, rf = d["roofline"], d["roofline_fwd"]
+    assert r["traffic_source"] is None or (r["traffic_source"]["measured_in_this_run"] is False and r["traffic_source"]["file"] == "profiles/traffic.json")
+    assert r["launch_us"] <= r["launch_us_event_interval"] and r["frac"] >= r["frac_event_interval"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert rf["kernel"] == "corr_fwd" and rf["pct_hbm"] > 0 and rf["pct_f32"] > 0 and rf["target_pct_hbm"] == 70.0
+    assert abs(rf["pct_hbm"] - 100 * rf["hbm"]["achieved"] / rf["hbm"]["peak"]) < 1e-6
     assert p.stderr.count("stub rank") == 2
 
 
