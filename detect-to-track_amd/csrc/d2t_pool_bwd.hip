@@ -36,6 +36,7 @@ namespace d2t { namespace tuned {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access, dword aligned
 
 D2T_KSTAMP_DEFINE(d2t_lab_pool_bwd_stamps)
 
@@ -1429,6 +1430,340 @@ static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* g
     return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------
+// PSROIPool backward, TILE form (round 6): ONE launch, no partial planes in memory, no workspace.  The row form above writes a plane
+// per (target, bin) and a second launch adds the planes of every input channel ((t+1) * bin is many-to-one, ps_roipool_cuda.cu:58:
+// at 21 targets 812 of the 1,029 (target, bin) pairs share their channel with another pair and 581 channels have no pair at all) --
+// 3.7-4.7x the op's bytes through HBM and two dependent small launches.  Here a workgroup owns (map row y, 16 map columns) and ALL 49
+// bins: the planes it would have written are 49 x nT x 16 floats and stay in LDS; its last phase adds them per input channel and
+// writes every channel's 64-byte run of gradIn once (zeros included).
+//   1. the RoIs' row / column bounds (bin_axis, as everywhere) -> one LDS list of (RoI, bin row) hits whose bin row contains y and
+//      whose cells reach the tile's columns, ordered by bin row then RoI, every bin row's run padded to whole k-steps of 4;
+//   2. chunks of the list: the hits' runs gradOut[r][t][i][0..6] -> LDS as A[j][hit][target] (two 16-byte loads per run, two chunks in
+//      flight), wave j multiplies D_(i,j)[t][x] += A[t][hit] * (x in cell ? 1 / n : 0) on the f32 matrix pipe; when the list moves on
+//      to the next bin row the wave's tile goes to the LDS planes;
+//   3. thread = input channel: sum its planes in ascending bin order (the order of k_psroipool_bwd_gather), store 16 columns.
+// Deterministic (fixed order, no atomics); <= 1 ulp per term from the reference's gradOut / n like the row form.
+// At most PT_MAXR RoIs (list entry = RoI | bin row << 10); larger calls keep the row / GEMM forms.
+// ---------------------------------------------------------------------------------------
+constexpr int PT_THREADS = KT * 64;                                  // 448: wave j = bin column j
+constexpr int PT_MAXR = 1024;
+constexpr int PT_PASSES = (PT_MAXR + PT_THREADS - 1) / PT_THREADS;   // 3 RoIs per thread at most
+constexpr int PT_NCNT = KT * PT_PASSES * KT;                         // 147 (bin row, pass, wave) counters
+
+static size_t ps_tiles_lds(int R, int nT)
+{
+    const size_t part = (size_t)KK * nT * 16 * 4, a = 2ull * KT * 32 * 16 * 4, e = 2ull * 32 * 8 * 8, cnt = 1024,
+                 list = (((size_t)KT * R + 4 * KT + 7) & ~(size_t)7) * 2;
+    return part + a + e + cnt + list;
+}
+
+template <int NCT>
+__global__ void __launch_bounds__(PT_THREADS)
+k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin, int R, int nT, int H, int W, int xtiles)
+{
+    constexpr int EC = 32 / NCT, TP = 16 * NCT;                      // hits per chunk x padded targets: 14 KB per buffer either way
+    extern __shared__ __attribute__((aligned(16))) float ptl[];
+    float* part = ptl;                                               // [49][nT][16]
+    float (*A)[KT][EC][TP] = reinterpret_cast<float (*)[KT][EC][TP]>(part + (size_t)KK * nT * 16);          // [2]
+    int (*ejb)[EC][8] = reinterpret_cast<int (*)[EC][8]>(reinterpret_cast<float*>(A) + 2 * KT * EC * TP);  // [2]
+    float (*esc)[EC][8] = reinterpret_cast<float (*)[EC][8]>(reinterpret_cast<int*>(ejb) + 2 * EC * 8);    // [2]
+    int* cnt = reinterpret_cast<int*>(esc) + 2 * EC * 8;             // [147] counts -> exclusive prefix; [160..167] run starts; [168..175] run bases; [176] list length
+    unsigned short* list = reinterpret_cast<unsigned short*>(cnt + 256);
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = wave;
+    // an XCD takes a contiguous run of (row, column tile): the gradOut runs of a RoI are read by the workgroups of the ~3 rows x ~2
+    // tiles it covers -- one L2 fetches them once
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int y = id / xtiles, xt = id - y * xtiles, x0 = 16 * xt;
+    D2T_KSTAMP(0);
+
+    // ---- 0. planes <- 0 (a bin no hit reaches keeps them)
+    {
+        f32x4* p4 = reinterpret_cast<f32x4*>(part);
+        const int n4 = KK * nT * 4;
+        for (int e = tid; e < n4; e += PT_THREADS) p4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- 1. the hit list.  Thread tid looks at RoIs tid + 448 p: which of its bin columns reach the tile, which of its bin rows hold y.
+    int rowm[PT_PASSES];
+    const int npass = (R + PT_THREADS - 1) / PT_THREADS;             // uniform, <= PT_PASSES
+#pragma unroll
+    for (int ps = 0; ps < PT_PASSES; ++ps) {
+        rowm[ps] = 0;
+        if (ps >= npass) continue;
+        const int r = ps * PT_THREADS + tid;
+        if (r < R) {
+            const f32x4 ro = *reinterpret_cast<const f32x4u*>(rois + 4 * (size_t)r);
+            bool reach = false;
+#pragma unroll
+            for (int q = 0; q < KT; ++q) {
+                int b0, b1;
+                bin_axis<float>(ro[1] - ro[3] / 2.0f, ro[3] / static_cast<float>(KT), q, W, b0, b1);
+                reach = reach || (b1 > b0 && b0 < x0 + 16 && b1 > x0);
+            }
+            if (reach) {
+#pragma unroll
+                for (int i = 0; i < KT; ++i) {
+                    int a0, a1;
+                    bin_axis<float>(ro[0] - ro[2] / 2.0f, ro[2] / static_cast<float>(KT), i, H, a0, a1);
+                    rowm[ps] |= (y >= a0 && y < a1) ? 1 << i : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            const unsigned long long mk = __ballot((rowm[ps] >> i) & 1);
+            if (lane == 0) cnt[(i * PT_PASSES + ps) * KT + wave] = __builtin_popcountll(mk);
+        }
+    }
+    for (int ps = npass; ps < PT_PASSES; ++ps)                      // passes that do not exist: empty
+        if (lane < KT) cnt[(lane * PT_PASSES + ps) * KT + wave] = 0;
+    __syncthreads();
+    if (wave == 0) {                                                 // exclusive prefix of the 147 counters in (bin row, pass, wave) order
+        int v[3], inc[3], carry = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = 64 * k + lane;
+            v[k] = idx < PT_NCNT ? cnt[idx] : 0;
+            inc[k] = v[k];
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const int o = __shfl_up(inc[k], dd, 64);
+                if (lane >= dd) inc[k] += o;
+            }
+            inc[k] += carry;
+            carry = __builtin_amdgcn_readlane(inc[k], 63);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the counts have been read by every lane
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (64 * k + lane < PT_NCNT) cnt[64 * k + lane] = inc[k] - v[k];
+        if (lane == 0) cnt[PT_NCNT] = carry;                         // all hits
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // run of bin row i: hits [base_i, base_{i+1}) of the unpadded order -> list positions [start_i, start_i + roundup4(len_i))
+        const int base = lane <= KT ? cnt[lane * PT_PASSES * KT] : 0;                  // lane 7: cnt[147] = the total
+        const int nxt = __shfl_down(base, 1, 64);
+        const int len = lane < KT ? nxt - base : 0, pad = (len + 3) & ~3;
+        int st = pad;
+#pragma unroll
+        for (int dd = 1; dd < 8; dd <<= 1) {
+            const int o = __shfl_up(st, dd, 64);
+            if (lane >= dd) st += o;
+        }
+        if (lane < KT) { cnt[160 + lane] = st - pad; cnt[168 + lane] = base; }
+        if (lane == KT - 1) cnt[176] = st;                           // padded list length
+        if (lane < KT)
+            for (int q = len; q < pad; ++q) list[st - pad + q] = 0xffffu;               // padding entries: no RoI
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PT_PASSES; ++ps) {
+        if (ps >= npass) continue;
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            const bool in = (rowm[ps] >> i) & 1;
+            const unsigned long long mk = __ballot(in);
+            if (in) {
+                const int pos = cnt[160 + i] + cnt[(i * PT_PASSES + ps) * KT + wave] - cnt[168 + i] + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+                list[pos] = (unsigned short)((ps * PT_THREADS + tid) | (i << 10));
+            }
+        }
+    }
+    __syncthreads();
+    const int total = cnt[176];                                      // multiple of 4
+    D2T_KSTAMP(1);
+
+    // ---- 2. chunks of EC list entries
+    const unsigned gout_bytes = (unsigned)((size_t)R * nT * KK * 4);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, gout_bytes, 0x00020000);
+    const int nchunk = (total + EC - 1) / EC;
+    constexpr int NLD = (2 * EC * TP + PT_THREADS - 1) / PT_THREADS;  // 3 loads of 16 bytes per thread and chunk
+    struct Stage { f32x4 run[NLD]; int gjb; float gsc; };
+    auto load_chunk = [&](Stage& sg, int c) {                        // global -> registers
+        const int e0 = c * EC;
+        sg.gjb = 0; sg.gsc = 0.f;
+        if (tid < EC * KT) {
+            const int e = tid / KT, q = tid - e * KT;
+            const int ent = e0 + e < total ? list[e0 + e] : 0xffff;
+            if (ent != 0xffff) {
+                const int r = ent & 1023, i = ent >> 10;
+                const f32x4 ro = *reinterpret_cast<const f32x4u*>(rois + 4 * (size_t)r);
+                int a0, a1, b0, b1;
+                bin_axis<float>(ro[0] - ro[2] / 2.0f, ro[2] / static_cast<float>(KT), i, H, a0, a1);
+                bin_axis<float>(ro[1] - ro[3] / 2.0f, ro[3] / static_cast<float>(KT), q, W, b0, b1);
+                const int hh = a1 - a0, ww = b1 - b0;
+                const bool any = hh > 0 && ww > 0 && b0 < x0 + 16 && b1 > x0;
+                // first column relative to the tile (+128) | width << 8 | reaches the tile << 16 | bin row << 24 (always: the k-step's bin row is read from it)
+                sg.gjb = (i << 24) | (any ? (b0 - x0 + 128) | (ww << 8) | (1 << 16) : 0);
+                sg.gsc = any ? 1.0f / static_cast<float>(hh * ww) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int sl = tid + k * PT_THREADS, rn = sl >> 1, half = sl & 1, e = rn / TP, t = rn - e * TP;
+            const int ent = rn < EC * TP && e0 + e < total ? list[e0 + e] : 0xffff;
+            const bool on = ent != 0xffff && t < nT;
+            const int off = on ? (((ent & 1023) * nT + t) * KK + (ent >> 10) * KT) * 4 + 12 * half : 0x7ffffff0;   // out of range: zeros
+            sg.run[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+        }
+    };
+    auto store_chunk = [&](const Stage& sg, int buf) {               // registers -> LDS
+        if (tid < EC * KT) {
+            const int e = tid / KT, q = tid - e * KT;
+            ejb[buf][e][q] = sg.gjb; esc[buf][e][q] = sg.gsc;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int sl = tid + k * PT_THREADS, rn = sl >> 1, half = sl & 1, e = rn / TP, t = rn - e * TP;
+            if (rn < EC * TP) {
+                if (half == 0) { A[buf][0][e][t] = sg.run[k][0]; A[buf][1][e][t] = sg.run[k][1]; A[buf][2][e][t] = sg.run[k][2]; A[buf][3][e][t] = sg.run[k][3]; }
+                else { A[buf][4][e][t] = sg.run[k][1]; A[buf][5][e][t] = sg.run[k][2]; A[buf][6][e][t] = sg.run[k][3]; }
+            }
+        }
+    };
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int i_acc = -1;                                                  // bin row the accumulators belong to (wave-uniform)
+    auto flush = [&]() {                                             // D[m = target 16 ct + 4 g + r][column n] -> the LDS plane of bin (i_acc, j)
+        if (i_acc < 0) return;
+        const int bin = i_acc * KT + j;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const f32x4 v = acc[ct];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * ct + 4 * g + r;
+                if (t < nT) part[((size_t)bin * nT + t) * 16 + n] = v[r];
+            }
+            // Cold path, as in the row form: a non-finite gradOut value times a 0 weight poisons columns outside its cell (the reference,
+            // ps_roipool_cuda.cu:131-139, only adds to the cell's own pixels); the wave recomputes the tile with exact membership.
+            if (__builtin_expect(__any(pool_nonfinite4(v)), 0)) {
+                for (int e = lane; e < 256; e += 64) {
+                    const int t = 16 * ct + (e >> 4), xx = x0 + (e & 15);
+                    if (t >= nT) continue;
+                    float a = 0.f;
+                    for (int r = 0; r < R; ++r) {
+                        const Bounds cb = psroi_cell<float>(rois + 4 * (size_t)r, i_acc, j, H, W, KT);
+                        const int nn = (cb.i1 - cb.i0) * (cb.j1 - cb.j0);
+                        if (y >= cb.i0 && y < cb.i1 && xx >= cb.j0 && xx < cb.j1)
+                            a = __builtin_fmaf(gout[((size_t)r * nT + t) * KK + bin], 1.0f / static_cast<float>(nn), a);
+                    }
+                    part[((size_t)bin * nT + t) * 16 + (e & 15)] = a;
+                }
+            }
+            acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    Stage sa, sb;                                                    // two chunks in flight: chunk c+2 is requested before the MFMAs of chunk c
+    if (nchunk > 0) { load_chunk(sa, 0); store_chunk(sa, 0); }
+    if (nchunk > 1) load_chunk(sa, 1);
+    __syncthreads();
+    D2T_KSTAMP(2);
+    auto chunk = [&](int c, Stage& nxt, Stage& nxt2) {               // nxt holds chunk c+1 (requested one chunk ago), nxt2 is free
+        const int buf = c & 1;
+        if (c + 2 < nchunk) load_chunk(nxt2, c + 2);
+        const int ne = total - c * EC < EC ? total - c * EC : EC;
+        const int nks = ne >> 2;                                     // uniform; the list is padded to whole k-steps
+        struct KOp { int jb; float sc; float a[NCT]; };
+        auto kfetch = [&](KOp& o, int ks) {
+            const int e = 4 * ks + g;
+            o.jb = ejb[buf][e][j];
+            o.sc = esc[buf][e][j];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) o.a[ct] = A[buf][j][e][16 * ct + n];
+        };
+        auto kstep = [&](const KOp& o) {
+            const int j0 = __builtin_amdgcn_readlane(o.jb, 0);       // the k-step's first entry is never padding
+            const int ik = j0 >> 24;
+            if (ik != i_acc) { flush(); i_acc = ik; }                // wave-uniform: the list has moved on to the next bin row
+            const int tm = (j0 | __builtin_amdgcn_readlane(o.jb, 16) | __builtin_amdgcn_readlane(o.jb, 32) | __builtin_amdgcn_readlane(o.jb, 48)) & (1 << 16);
+            if (!tm) return;                                         // no hit of this k-step reaches the tile in bin column j
+            const float b = (unsigned)(n + 128 - (o.jb & 0xff)) < (((unsigned)o.jb >> 8) & 0xffu) ? o.sc : 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[ct], b, acc[ct], 0, 0, 0);
+        };
+        KOp ka, kb;
+        if (nks > 0) kfetch(ka, 0);
+        for (int ks = 0; ks < nks; ks += 2) {
+            if (ks + 1 < nks) kfetch(kb, ks + 1);
+            kstep(ka);
+            if (ks + 1 >= nks) break;
+            if (ks + 2 < nks) kfetch(ka, ks + 2);
+            kstep(kb);
+        }
+        if (c + 1 < nchunk) store_chunk(nxt, buf ^ 1);
+        __syncthreads();
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk(c, sa, sb);
+        if (c + 1 < nchunk) chunk(c + 1, sb, sa);
+    }
+    flush();
+    __syncthreads();
+    D2T_KSTAMP(3);
+
+    // ---- 3. thread = input channel: the planes (t, bin) with (t + 1) bin == ch, ascending bin (channel 0: bin 0 of every target)
+    const int nch = nT * KK;
+    const bool whole = x0 + 16 <= W;
+    for (int ch = tid; ch < nch; ch += PT_THREADS) {
+        f32x4 o[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        auto add = [&](int bin, int t) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)bin * nT + t) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] += p[q];
+        };
+        if (ch == 0) {
+            for (int t = 0; t < nT; ++t) add(0, t);
+        } else {
+#pragma unroll
+            for (int bin = 1; bin < KK; ++bin) {
+                const int q = ch / bin;                              // constant divisor: a multiply
+                if (q * bin == ch && q <= nT) add(bin, q - 1);
+            }
+        }
+        float* dst = gin + ((size_t)ch * H + y) * W + x0;
+        if (whole) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4u*>(dst + 4 * q) = o[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (x0 + 4 * q + r < W) dst[4 * q + r] = o[q][r];
+        }
+    }
+    D2T_KSTAMP(4);
+}
+
+static bool psroipool_bwd_tiles_supported(int R, int nT, int H, int W, int k)
+{
+    return k == KT && R >= 1 && R <= PT_MAXR && nT >= 1 && nT <= 32 && H >= 1 && H <= 32767 && W >= 1 && W <= 127 &&
+           1LL * R * nT * KK * 4 < 0x7ffffff0LL && 1LL * nT * KK * H * W < 0x7fffffffLL && 1LL * H * ((W + 15) / 16) < 0x7fffffffLL &&
+           ps_tiles_lds(R, nT) <= (size_t)LDS_MAX;
+}
+
+static int psroipool_bwd_tiles_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, hipStream_t st)
+{
+    const int xtiles = (W + 15) / 16;
+    const size_t lds = ps_tiles_lds(R, nT);
+    if (nT <= 16) {
+        D2T_ENSURE_DYNAMIC_LDS(k_ps_bwd_tiles<1>, LDS_MAX);
+        hipLaunchKernelGGL(k_ps_bwd_tiles<1>, dim3(H * xtiles), dim3(PT_THREADS), lds, st, gout, rois, gin, R, nT, H, W, xtiles);
+    } else {
+        D2T_ENSURE_DYNAMIC_LDS(k_ps_bwd_tiles<2>, LDS_MAX);
+        hipLaunchKernelGGL(k_ps_bwd_tiles<2>, dim3(H * xtiles), dim3(PT_THREADS), lds, st, gout, rois, gin, R, nT, H, W, xtiles);
+    }
+    return launch_status();
+}
+
 // Which of the three backward designs runs (ps_bwd_design below).  History of the sorted lists vs the planes:
 // the sorted-corner-list kernels (d2t_pool_sorted.hip) do
 // work proportional to the RoI corners per plane (4R) plus a fixed cost of three launches and a
@@ -1445,17 +1780,20 @@ static int ps_bwd_forced()
     static const int v = [] {
         const char* e = lab_env_str("D2T_PS_BWD");                       // -DD2T_LAB only
         if (!e) return 0;
-        return !strcmp(e, "planes") ? 1 : !strcmp(e, "sorted") ? 2 : !strcmp(e, "gemm") ? 3 : !strcmp(e, "rows") ? 4 : 0;
+        return !strcmp(e, "planes") ? 1 : !strcmp(e, "sorted") ? 2 : !strcmp(e, "gemm") ? 3 : !strcmp(e, "rows") ? 4 : !strcmp(e, "tiles") ? 5 : 0;
     }();
     return v;
 }
 
-// 0 = plane kernels, 1 = sorted corner lists, 2 = GEMM behind three pre-passes, 3 = row form (one launch + gather)
+// 0 = plane kernels, 1 = sorted corner lists, 2 = GEMM behind three pre-passes, 3 = row form (one launch + gather), 4 = tile form (ONE launch)
 static int ps_bwd_design(int R, int nT, int H, int W, int k)
 {
     const bool g = psroipool_bwd_gemm_supported(R, nT, H, W, k), s = psroipool_bwd_sorted_supported(R, nT, H, W, k),
-               p = psroipool_bwd_planes_supported(R, nT, H, W, k), rw = psroipool_bwd_rows_supported(R, nT, H, W, k);
+               p = psroipool_bwd_planes_supported(R, nT, H, W, k), rw = psroipool_bwd_rows_supported(R, nT, H, W, k),
+               tl = psroipool_bwd_tiles_supported(R, nT, H, W, k);
     const int f = ps_bwd_forced();
+    if (f == 5 && tl) return 4;
+    if (f == 0 && tl) return 4;                                        // round 6: up to 1,024 RoIs, one launch, no workspace
     if (f == 4 && rw) return 3;
     if (f == 3 && g) return 2;
     if (f == 2 && s) return 1;
@@ -1472,13 +1810,14 @@ static int ps_bwd_design(int R, int nT, int H, int W, int k)
 
 bool psroipool_bwd_supported(int R, int nT, int H, int W, int k)
 {
-    return psroipool_bwd_rows_supported(R, nT, H, W, k) || psroipool_bwd_gemm_supported(R, nT, H, W, k) ||
+    return psroipool_bwd_tiles_supported(R, nT, H, W, k) || psroipool_bwd_rows_supported(R, nT, H, W, k) || psroipool_bwd_gemm_supported(R, nT, H, W, k) ||
            psroipool_bwd_sorted_supported(R, nT, H, W, k) || psroipool_bwd_planes_supported(R, nT, H, W, k);
 }
 
 size_t psroipool_bwd_ws_bytes(int R, int nT, int H, int W, int k)
 {
     const int d = ps_bwd_design(R, nT, H, W, k);
+    if (d == 4) return 0;
     if (d == 3) return psroipool_bwd_rows_ws_bytes(R, nT, H, W, k);
     return d == 2 ? psroipool_bwd_gemm_ws_bytes(R, nT, H, W, k) : d == 1 ? psroipool_bwd_sorted_ws_bytes(R, nT, H, W, k)
                                                                          : psroipool_bwd_planes_ws_bytes(R, nT, H, W, k);
@@ -1488,6 +1827,7 @@ int psroipool_bwd_f32(const float* gout, const float* rois, float* gin, int R, i
                       void* ws, hipStream_t st)
 {
     const int d = ps_bwd_design(R, nT, H, W, k);
+    if (d == 4) return psroipool_bwd_tiles_f32(gout, rois, gin, R, nT, H, W, st);
     if (d == 3) return psroipool_bwd_rows_f32(gout, rois, gin, R, nT, H, W, ws, st);
     if (d == 2) return psroipool_bwd_gemm_f32(gout, rois, gin, R, nT, H, W, ws, st);
     if (d == 1) return psroipool_bwd_sorted_f32(gout, rois, gin, R, nT, H, W, k, ws, st);

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Which call of a training step is not run-to-run reproducible?  Runs DataParallelTrainer.train_step twice in ONE process on the same
+pairs from the same weights (lr 0), records every call into libd2t_ops.so (inputs, outputs) and the gradients, and reports the first
+call whose inputs are bit-equal but whose outputs differ, then the parameters whose gradients differ."""
+import sys
+from pathlib import Path
+import torch
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
+sys.path.insert(0, str(ROOT / "tests"))
+import dp_equivalence_main as M
+from detect_to_track.models import _ext
+from detect_to_track.training import BatchLoader, SyntheticPairManager
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+model, trainer, n_anchor = M.build(dev)
+manager = SyntheticPairManager(4, (M.H, M.W), n_anchor, M.R, M.T, 30, dev, seed=11)
+minibatch = next(iter(BatchLoader(manager, 4, 0, 1, seed=5)))
+names = ("pointwise_correlation_levels_forward", "pointwise_correlation_levels_backward", "roipool_forward", "roipool_backward",
+         "ps_roipool_forward", "ps_roipool_backward", "region_filter", "region_filter_batched")
+saved = {n: getattr(_ext, n) for n in names}
+log = []
+keep = lambda v: [keep(x) for x in v] if isinstance(v, (list, tuple)) else (v.detach().clone() if torch.is_tensor(v) else v)
+def wrap(name):
+    def f(*a, **k):
+        out = saved[name](*a, **k)
+        log.append((name, keep(list(a)), keep(out)))
+        return out
+    return f
+for n in names:
+    setattr(_ext, n, wrap(n))
+def same(a, b):
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+    if torch.is_tensor(a):
+        return a.shape == b.shape and torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+    return a == b
+runs = []
+for it in range(2):
+    log.clear()
+    trainer.train_step(minibatch)
+    torch.cuda.synchronize()
+    runs.append((list(log), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}))
+(l0, g0), (l1, g1) = runs
+print("calls", len(l0), len(l1))
+for k, (c0, c1) in enumerate(zip(l0, l1)):
+    i_same, o_same = same(c0[1], c1[1]), same(c0[2], c1[2])
+    shapes = [tuple(x.shape) for x in c0[1] if torch.is_tensor(x)]
+    if not (i_same and o_same):
+        print(k, c0[0], "inputs equal" if i_same else "INPUTS DIFFER", "outputs equal" if o_same else "OUTPUTS DIFFER", shapes)
+bad = [(float((g0[n] - g1[n]).abs().max() / g0[n].abs().max().clamp_min(1e-30)), n) for n in g0 if not torch.equal(g0[n], g1[n])]
+print("parameters whose gradients differ:", len(bad), "of", len(g0))
+for e, n in sorted(bad, reverse=True)[:10]:
+    print(f"  {n}: {e:.3e}")
+# each op's backward alone, repeated on the recorded inputs
+for k, c in enumerate(l0):
+    if c[0].endswith("backward"):
+        outs = [saved[c[0]](*c[1]) for _ in range(3)]
+        torch.cuda.synchronize()
+        print(k, c[0], [tuple(x.shape) for x in c[1] if torch.is_tensor(x)], "repeatable" if all(same(keep(o), keep(outs[0])) for o in outs) else "NOT REPEATABLE",
+              "== recorded" if same(keep(outs[0]), c[2]) else "!= recorded")
