@@ -282,10 +282,11 @@ int d2t_roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, i
     if (ws_misaligned(ws)) return D2T_EINVAL;
     int rc = check_pool(fm, rois, out, R, C, H, W, k);
     if (rc != D2T_OK) return rc;
-    // The tuned forward builds a summed-area table of every channel (the whole map is read once): for
-    // a handful of RoIs (the tracker pools ~8 boxes of a 1891-channel map) the thread-per-output
-    // kernel, which only touches the boxes' pixels, is the faster one.
-    const bool few_rois = (impl == D2T_IMPL_AUTO || impl == D2T_IMPL_FAST) && R < 32;
+    // The summed-area forward (k != 7, or maps too large for the direct kernel) builds a table of every channel: for a handful of RoIs the
+    // thread-per-output kernel, which only touches the boxes' pixels, is the faster one.  The direct k = 7 kernel (round 6) is not: the
+    // tracker's 8 boxes of a 1891-channel map take 9 us there against 21 us (profiles/r06_*).
+    const bool direct = k == 7 && tuned::roipool_fwd_direct_supported(R, C, H, W, k);
+    const bool few_rois = (impl == D2T_IMPL_AUTO || impl == D2T_IMPL_FAST) && R < 32 && !direct;
     if (impl != D2T_IMPL_GENERIC && !few_rois && tuned::roipool_fwd_supported(R, C, H, W, k)) {
         if (ws_bytes < tuned::roipool_fwd_ws_bytes(R, C, H, W, k) || (!ws && ws_bytes)) return D2T_EWS;
         return tuned::roipool_fwd_f32(fm, rois, out, R, C, H, W, k, ws, as_stream(stream));

@@ -37,6 +37,7 @@ namespace d2t { namespace tuned {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access, dword aligned
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 D2T_KSTAMP_DEFINE(d2t_lab_pool_bwd_stamps)
 
@@ -844,14 +845,31 @@ k_psroipool_bwd_gather(const float* __restrict__ part, float* __restrict__ gin, 
     __syncthreads();
     const int ns = nsrc;
     const size_t slice = (size_t)nT * KK * HW;                       // partial planes of one RoI slice (nslice = 1: the planes themselves)
+    // the planes of a channel are read EIGHT at a time (all loads issued, then added in order): a thread that walks its <= 31 planes one
+    // dependent load after the other spends a memory round trip on each (round 6: with one workgroup per channel instead of ten the op took 77 us)
+    const int nsrc_all = ch == 0 ? nT : ns;
+    auto plane_of = [&](int k) { return ch == 0 ? k * KK : srcs[k]; };   // bin 0 of every target / the listed planes
     for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
         float a = 0.f;
-        if (ch == 0) {                                               // bin 0 of every target
-            for (int t = 0; t < nT; ++t)
-                for (int sl = 0; sl < nslice; ++sl) a += part[sl * slice + (size_t)(t * KK) * HW + p];
-        } else {
-            for (int k = 0; k < ns; ++k)
-                for (int sl = 0; sl < nslice; ++sl) a += part[sl * slice + (size_t)srcs[k] * HW + p];
+        if (nslice == 1) {
+            for (int k0 = 0; k0 < nsrc_all; k0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = k0 + k < nsrc_all ? part[(size_t)plane_of(k0 + k) * HW + p] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a = k0 + k < nsrc_all ? a + v[k] : a;
+            }
+        } else {                                                     // RoI slices: plane by plane, the slices of a plane ascending
+            for (int k = 0; k < nsrc_all; ++k) {
+                const size_t o = (size_t)plane_of(k) * HW + p;
+                for (int s0 = 0; s0 < nslice; s0 += 4) {
+                    float w[4];
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) w[sl] = s0 + sl < nslice ? part[(s0 + sl) * slice + o] : 0.f;
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) a = s0 + sl < nslice ? a + w[sl] : a;
+                }
+            }
         }
         gin[(size_t)ch * HW + p] = a;
     }
@@ -1426,7 +1444,9 @@ static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* g
     int rc = launch_status();
     if (rc != D2T_OK) return rc;
     const int HW = H * W;
-    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3((HW + 255) / 256, nT * KK), dim3(256), 0, st, part, gin, nT, HW, nseg);
+    const int gx_all = (HW + 255) / 256, gx_knob = lab_env_int("D2T_PS_GATHER_GX", 0);   // scan builds: workgroups per channel
+    const int gx = gx_knob > 0 && gx_knob < gx_all ? gx_knob : gx_all;
+    hipLaunchKernelGGL(k_psroipool_bwd_gather, dim3(gx, nT * KK), dim3(256), 0, st, part, gin, nT, HW, nseg);
     return launch_status();
 }
 
@@ -1437,39 +1457,42 @@ static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* g
 // 3.7-4.7x the op's bytes through HBM and two dependent small launches.  Here a workgroup owns (map row y, 16 map columns) and ALL 49
 // bins: the planes it would have written are 49 x nT x 16 floats and stay in LDS; its last phase adds them per input channel and
 // writes every channel's 64-byte run of gradIn once (zeros included).
-//   1. the RoIs' row / column bounds (bin_axis, as everywhere) -> one LDS list of (RoI, bin row) hits whose bin row contains y and
-//      whose cells reach the tile's columns, ordered by bin row then RoI, every bin row's run padded to whole k-steps of 4;
+//   1. thread = RoI: the row / column bounds of its 7 + 7 bin rows / columns (bin_axis, as everywhere) -> an LDS table; wave i then
+//      lists the RoIs whose bin row i holds y and whose cells reach the tile's columns: one list, ordered by bin row then RoI, every bin
+//      row's run padded to whole k-steps of 4;
 //   2. chunks of the list: the hits' runs gradOut[r][t][i][0..6] -> LDS as A[j][hit][target] (two 16-byte loads per run, two chunks in
 //      flight), wave j multiplies D_(i,j)[t][x] += A[t][hit] * (x in cell ? 1 / n : 0) on the f32 matrix pipe; when the list moves on
 //      to the next bin row the wave's tile goes to the LDS planes;
-//   3. thread = input channel: sum its planes in ascending bin order (the order of k_psroipool_bwd_gather), store 16 columns.
+//   3. thread = input channel: which targets feed it (t + 1 divides ch, ch / (t + 1) <= 48) as a bit mask, then its planes in ascending
+//      bin order (the order of k_psroipool_bwd_gather), 16 columns stored.
 // Deterministic (fixed order, no atomics); <= 1 ulp per term from the reference's gradOut / n like the row form.
-// At most PT_MAXR RoIs (list entry = RoI | bin row << 10); larger calls keep the row / GEMM forms.
+// At most PT_MAXR RoIs (list entry = RoI | bin row << 10), maps up to 255 x 255, what fits the LDS; larger calls keep the row / GEMM forms.
 // ---------------------------------------------------------------------------------------
-constexpr int PT_THREADS = KT * 64;                                  // 448: wave j = bin column j
+constexpr int PT_THREADS = KT * 64;                                  // 448: wave j = bin column j (phase 2), wave i = bin row i (phase 1)
 constexpr int PT_MAXR = 1024;
 constexpr int PT_PASSES = (PT_MAXR + PT_THREADS - 1) / PT_THREADS;   // 3 RoIs per thread at most
-constexpr int PT_NCNT = KT * PT_PASSES * KT;                         // 147 (bin row, pass, wave) counters
 
-static size_t ps_tiles_lds(int R, int nT)
+static size_t ps_tiles_lds(int R, int nT, int ec)
 {
-    const size_t part = (size_t)KK * nT * 16 * 4, a = 2ull * KT * 32 * 16 * 4, e = 2ull * 32 * 8 * 8, cnt = 1024,
-                 list = (((size_t)KT * R + 4 * KT + 7) & ~(size_t)7) * 2;
-    return part + a + e + cnt + list;
+    const int tp = nT <= 16 ? 16 : 32;
+    const size_t part = (size_t)KK * nT * 16 * 4, a = 2ull * KT * ec * tp * 4, e = 2ull * ec * 8 * 8, misc = 256,
+                 geo = (size_t)R * 32, list = (((size_t)KT * R + 4 * KT + 7) & ~(size_t)7) * 2;
+    return part + a + e + misc + geo + list;
 }
 
-template <int NCT>
+template <int NCT, int EC>
 __global__ void __launch_bounds__(PT_THREADS)
 k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin, int R, int nT, int H, int W, int xtiles)
 {
-    constexpr int EC = 32 / NCT, TP = 16 * NCT;                      // hits per chunk x padded targets: 14 KB per buffer either way
+    constexpr int TP = 16 * NCT;                                     // padded targets
     extern __shared__ __attribute__((aligned(16))) float ptl[];
     float* part = ptl;                                               // [49][nT][16]
     float (*A)[KT][EC][TP] = reinterpret_cast<float (*)[KT][EC][TP]>(part + (size_t)KK * nT * 16);          // [2]
     int (*ejb)[EC][8] = reinterpret_cast<int (*)[EC][8]>(reinterpret_cast<float*>(A) + 2 * KT * EC * TP);  // [2]
     float (*esc)[EC][8] = reinterpret_cast<float (*)[EC][8]>(reinterpret_cast<int*>(ejb) + 2 * EC * 8);    // [2]
-    int* cnt = reinterpret_cast<int*>(esc) + 2 * EC * 8;             // [147] counts -> exclusive prefix; [160..167] run starts; [168..175] run bases; [176] list length
-    unsigned short* list = reinterpret_cast<unsigned short*>(cnt + 256);
+    int* misc = reinterpret_cast<int*>(esc) + 2 * EC * 8;            // [0..6] hits per bin row, [8..14] run starts, [15] list length
+    unsigned short* geo = reinterpret_cast<unsigned short*>(misc + 64);   // [R][16]: row bounds of i (lo | hi << 8), column bounds of j, reaches-the-tile
+    unsigned short* list = geo + (size_t)R * 16;
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1482,108 +1505,86 @@ k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, f
     const int y = id / xtiles, xt = id - y * xtiles, x0 = 16 * xt;
     D2T_KSTAMP(0);
 
-    // ---- 0. planes <- 0 (a bin no hit reaches keeps them)
+    // ---- 1a. thread = RoI: geometry table (the loads go out first, the planes are zeroed under their latency)
+    f32x4 ro[PT_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PT_PASSES; ++ps) {
+        const int r = ps * PT_THREADS + tid;
+        ro[ps] = r < R ? f32x4(*reinterpret_cast<const f32x4u*>(rois + 4 * (size_t)r)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     {
-        f32x4* p4 = reinterpret_cast<f32x4*>(part);
+        f32x4* p4 = reinterpret_cast<f32x4*>(part);                  // a bin no hit reaches keeps its zeros
         const int n4 = KK * nT * 4;
         for (int e = tid; e < n4; e += PT_THREADS) p4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // ---- 1. the hit list.  Thread tid looks at RoIs tid + 448 p: which of its bin columns reach the tile, which of its bin rows hold y.
-    int rowm[PT_PASSES];
-    const int npass = (R + PT_THREADS - 1) / PT_THREADS;             // uniform, <= PT_PASSES
 #pragma unroll
     for (int ps = 0; ps < PT_PASSES; ++ps) {
-        rowm[ps] = 0;
-        if (ps >= npass) continue;
         const int r = ps * PT_THREADS + tid;
+        if (r >= R) continue;
+        unsigned gq[8];
+        bool reach = false;
+        unsigned cb[KT], rb[KT];
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            int b0, b1;
+            bin_axis<float>(ro[ps][1] - ro[ps][3] / 2.0f, ro[ps][3] / static_cast<float>(KT), q, W, b0, b1);
+            reach = reach || (b1 > b0 && b0 < x0 + 16 && b1 > x0);
+            cb[q] = (unsigned)b0 | ((unsigned)b1 << 8);
+        }
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+            int a0 = 0, a1 = 0;
+            if (reach) bin_axis<float>(ro[ps][0] - ro[ps][2] / 2.0f, ro[ps][2] / static_cast<float>(KT), i, H, a0, a1);
+            rb[i] = (unsigned)a0 | ((unsigned)a1 << 8);
+        }
+        gq[0] = rb[0] | (rb[1] << 16); gq[1] = rb[2] | (rb[3] << 16); gq[2] = rb[4] | (rb[5] << 16); gq[3] = rb[6] | (cb[0] << 16);
+        gq[4] = cb[1] | (cb[2] << 16); gq[5] = cb[3] | (cb[4] << 16); gq[6] = cb[5] | (cb[6] << 16); gq[7] = reach ? 1u : 0u;
+        u32x4* gp = reinterpret_cast<u32x4*>(geo + (size_t)r * 16);
+        gp[0] = u32x4{gq[0], gq[1], gq[2], gq[3]};
+        gp[1] = u32x4{gq[4], gq[5], gq[6], gq[7]};
+    }
+    __syncthreads();
+    // ---- 1b. wave i: the RoIs whose bin row i holds y (and that reach the tile), ascending; bit `it` of mybits = RoI 64 it + lane is one
+    const int i_w = wave, nit = (R + 63) >> 6;                       // <= 16 iterations
+    unsigned mybits = 0;
+    int mycount = 0;
+    for (int it = 0; it < nit; ++it) {
+        const int r = 64 * it + lane;
+        bool in = false;
         if (r < R) {
-            const f32x4 ro = *reinterpret_cast<const f32x4u*>(rois + 4 * (size_t)r);
-            bool reach = false;
-#pragma unroll
-            for (int q = 0; q < KT; ++q) {
-                int b0, b1;
-                bin_axis<float>(ro[1] - ro[3] / 2.0f, ro[3] / static_cast<float>(KT), q, W, b0, b1);
-                reach = reach || (b1 > b0 && b0 < x0 + 16 && b1 > x0);
-            }
-            if (reach) {
-#pragma unroll
-                for (int i = 0; i < KT; ++i) {
-                    int a0, a1;
-                    bin_axis<float>(ro[0] - ro[2] / 2.0f, ro[2] / static_cast<float>(KT), i, H, a0, a1);
-                    rowm[ps] |= (y >= a0 && y < a1) ? 1 << i : 0;
-                }
-            }
+            const unsigned rbv = geo[(size_t)r * 16 + i_w];
+            in = geo[(size_t)r * 16 + 14] != 0 && y >= (int)(rbv & 255u) && y < (int)(rbv >> 8);
         }
-#pragma unroll
-        for (int i = 0; i < KT; ++i) {
-            const unsigned long long mk = __ballot((rowm[ps] >> i) & 1);
-            if (lane == 0) cnt[(i * PT_PASSES + ps) * KT + wave] = __builtin_popcountll(mk);
-        }
+        mybits |= in ? 1u << it : 0u;
+        mycount += __builtin_popcountll(__ballot(in));
     }
-    for (int ps = npass; ps < PT_PASSES; ++ps)                      // passes that do not exist: empty
-        if (lane < KT) cnt[(lane * PT_PASSES + ps) * KT + wave] = 0;
+    if (lane == 0) misc[i_w] = mycount;
     __syncthreads();
-    if (wave == 0) {                                                 // exclusive prefix of the 147 counters in (bin row, pass, wave) order
-        int v[3], inc[3], carry = 0;
+    int start = 0, total = 0;                                        // this wave's run in the list; the padded length of the list
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int idx = 64 * k + lane;
-            v[k] = idx < PT_NCNT ? cnt[idx] : 0;
-            inc[k] = v[k];
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const int o = __shfl_up(inc[k], dd, 64);
-                if (lane >= dd) inc[k] += o;
-            }
-            inc[k] += carry;
-            carry = __builtin_amdgcn_readlane(inc[k], 63);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the counts have been read by every lane
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (64 * k + lane < PT_NCNT) cnt[64 * k + lane] = inc[k] - v[k];
-        if (lane == 0) cnt[PT_NCNT] = carry;                         // all hits
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // run of bin row i: hits [base_i, base_{i+1}) of the unpadded order -> list positions [start_i, start_i + roundup4(len_i))
-        const int base = lane <= KT ? cnt[lane * PT_PASSES * KT] : 0;                  // lane 7: cnt[147] = the total
-        const int nxt = __shfl_down(base, 1, 64);
-        const int len = lane < KT ? nxt - base : 0, pad = (len + 3) & ~3;
-        int st = pad;
-#pragma unroll
-        for (int dd = 1; dd < 8; dd <<= 1) {
-            const int o = __shfl_up(st, dd, 64);
-            if (lane >= dd) st += o;
-        }
-        if (lane < KT) { cnt[160 + lane] = st - pad; cnt[168 + lane] = base; }
-        if (lane == KT - 1) cnt[176] = st;                           // padded list length
-        if (lane < KT)
-            for (int q = len; q < pad; ++q) list[st - pad + q] = 0xffffu;               // padding entries: no RoI
+    for (int i = 0; i < KT; ++i) {
+        const int c = misc[i], pad = (c + 3) & ~3;
+        start = i == i_w ? total : start;
+        total += pad;
     }
-    __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < PT_PASSES; ++ps) {
-        if (ps >= npass) continue;
-#pragma unroll
-        for (int i = 0; i < KT; ++i) {
-            const bool in = (rowm[ps] >> i) & 1;
+    {
+        int pos = start;
+        for (int it = 0; it < nit; ++it) {
+            const bool in = (mybits >> it) & 1u;
             const unsigned long long mk = __ballot(in);
-            if (in) {
-                const int pos = cnt[160 + i] + cnt[(i * PT_PASSES + ps) * KT + wave] - cnt[168 + i] + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
-                list[pos] = (unsigned short)((ps * PT_THREADS + tid) | (i << 10));
-            }
+            if (in) list[pos + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (unsigned short)((64 * it + lane) | (i_w << 10));
+            pos += __builtin_popcountll(mk);
         }
+        if (lane < ((mycount + 3) & ~3) - mycount) list[pos + lane] = 0xffffu;   // padding entries: no RoI
     }
     __syncthreads();
-    const int total = cnt[176];                                      // multiple of 4
     D2T_KSTAMP(1);
 
     // ---- 2. chunks of EC list entries
     const unsigned gout_bytes = (unsigned)((size_t)R * nT * KK * 4);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, gout_bytes, 0x00020000);
     const int nchunk = (total + EC - 1) / EC;
-    constexpr int NLD = (2 * EC * TP + PT_THREADS - 1) / PT_THREADS;  // 3 loads of 16 bytes per thread and chunk
+    constexpr int NLD = (2 * EC * TP + PT_THREADS - 1) / PT_THREADS;  // loads of 16 bytes per thread and chunk
     struct Stage { f32x4 run[NLD]; int gjb; float gsc; };
     auto load_chunk = [&](Stage& sg, int c) {                        // global -> registers
         const int e0 = c * EC;
@@ -1593,14 +1594,12 @@ k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, f
             const int ent = e0 + e < total ? list[e0 + e] : 0xffff;
             if (ent != 0xffff) {
                 const int r = ent & 1023, i = ent >> 10;
-                const f32x4 ro = *reinterpret_cast<const f32x4u*>(rois + 4 * (size_t)r);
-                int a0, a1, b0, b1;
-                bin_axis<float>(ro[0] - ro[2] / 2.0f, ro[2] / static_cast<float>(KT), i, H, a0, a1);
-                bin_axis<float>(ro[1] - ro[3] / 2.0f, ro[3] / static_cast<float>(KT), q, W, b0, b1);
+                const unsigned rbv = geo[(size_t)r * 16 + i], cbv = geo[(size_t)r * 16 + 7 + q];
+                const int a0 = rbv & 255u, a1 = rbv >> 8, b0 = cbv & 255u, b1 = cbv >> 8;
                 const int hh = a1 - a0, ww = b1 - b0;
                 const bool any = hh > 0 && ww > 0 && b0 < x0 + 16 && b1 > x0;
-                // first column relative to the tile (+128) | width << 8 | reaches the tile << 16 | bin row << 24 (always: the k-step's bin row is read from it)
-                sg.gjb = (i << 24) | (any ? (b0 - x0 + 128) | (ww << 8) | (1 << 16) : 0);
+                // first column relative to the tile (+256) | width << 9 | reaches the tile << 17 | bin row << 24 (always: the k-step's bin row is read from it)
+                sg.gjb = (i << 24) | (any ? (b0 - x0 + 256) | (ww << 9) | (1 << 17) : 0);
                 sg.gsc = any ? 1.0f / static_cast<float>(hh * ww) : 0.f;
             }
         }
@@ -1662,13 +1661,35 @@ k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, f
         }
     };
     Stage sa, sb;                                                    // two chunks in flight: chunk c+2 is requested before the MFMAs of chunk c
-    if (nchunk > 0) { load_chunk(sa, 0); store_chunk(sa, 0); }
+    if (nchunk > 0) load_chunk(sa, 0);
+    // Phase 3's bookkeeping, under the latency of the first loads: thread = input channel ch = 1 + tid + 448 k; bit m-1 of cmask[k] = target
+    // m-1 feeds it through bin ch / m (m divides ch, ch / m <= 48).
+    const int nch = nT * KK;
+    constexpr int NCHI = (32 * KK + PT_THREADS - 1) / PT_THREADS;    // 4 channels per thread at most
+    unsigned cmask[NCHI];
+#pragma unroll
+    for (int k = 0; k < NCHI; ++k) {
+        const int ch = 1 + tid + k * PT_THREADS;
+        cmask[k] = 0;
+        if (ch < nch) {
+            const float chf = (float)ch;
+#pragma unroll
+            for (int m = 1; m <= TP; ++m) {
+                const int q = (int)(chf * (1.0f / (float)m) + 0.25f);    // ch / m where m divides ch (ch < 2^11: the product is off by < 1e-3)
+                cmask[k] |= (m <= nT && q * m == ch && q < KK) ? 1u << (m - 1) : 0u;
+            }
+        }
+    }
+    if (nchunk > 0) store_chunk(sa, 0);
     if (nchunk > 1) load_chunk(sa, 1);
     __syncthreads();
     D2T_KSTAMP(2);
+    D2T_KSTAMP_ONLY(unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, tl = 0, tm = 0, ts = 0, tb = 0;)
     auto chunk = [&](int c, Stage& nxt, Stage& nxt2) {               // nxt holds chunk c+1 (requested one chunk ago), nxt2 is free
         const int buf = c & 1;
+        D2T_KCLK(k0);
         if (c + 2 < nchunk) load_chunk(nxt2, c + 2);
+        D2T_KCLK(k1);
         const int ne = total - c * EC < EC ? total - c * EC : EC;
         const int nks = ne >> 2;                                     // uniform; the list is padded to whole k-steps
         struct KOp { int jb; float sc; float a[NCT]; };
@@ -1683,9 +1704,9 @@ k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, f
             const int j0 = __builtin_amdgcn_readlane(o.jb, 0);       // the k-step's first entry is never padding
             const int ik = j0 >> 24;
             if (ik != i_acc) { flush(); i_acc = ik; }                // wave-uniform: the list has moved on to the next bin row
-            const int tm = (j0 | __builtin_amdgcn_readlane(o.jb, 16) | __builtin_amdgcn_readlane(o.jb, 32) | __builtin_amdgcn_readlane(o.jb, 48)) & (1 << 16);
+            const int tm = (j0 | __builtin_amdgcn_readlane(o.jb, 16) | __builtin_amdgcn_readlane(o.jb, 32) | __builtin_amdgcn_readlane(o.jb, 48)) & (1 << 17);
             if (!tm) return;                                         // no hit of this k-step reaches the tile in bin column j
-            const float b = (unsigned)(n + 128 - (o.jb & 0xff)) < (((unsigned)o.jb >> 8) & 0xffu) ? o.sc : 0.f;
+            const float b = (unsigned)(n + 256 - (o.jb & 0x1ff)) < (((unsigned)o.jb >> 9) & 0xffu) ? o.sc : 0.f;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[ct], b, acc[ct], 0, 0, 0);
         };
@@ -1698,8 +1719,12 @@ k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, f
             if (ks + 2 < nks) kfetch(ka, ks + 2);
             kstep(kb);
         }
+        D2T_KCLK(k2);
         if (c + 1 < nchunk) store_chunk(nxt, buf ^ 1);
+        D2T_KCLK(k3);
         __syncthreads();
+        D2T_KCLK(k4);
+        D2T_KSTAMP_ONLY(tl += k1 - k0; tm += k2 - k1; ts += k3 - k2; tb += k4 - k3;)
     };
     for (int c = 0; c < nchunk; c += 2) {
         chunk(c, sa, sb);
@@ -1708,59 +1733,83 @@ k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, f
     flush();
     __syncthreads();
     D2T_KSTAMP(3);
+    D2T_KSTAMP_PUT(5, tl); D2T_KSTAMP_PUT(6, tm); D2T_KSTAMP_PUT(7, ts); D2T_KSTAMP_PUT(8, tb); D2T_KSTAMP_PUT(9, (unsigned long long)nchunk);
 
-    // ---- 3. thread = input channel: the planes (t, bin) with (t + 1) bin == ch, ascending bin (channel 0: bin 0 of every target)
-    const int nch = nT * KK;
+    // ---- 3. thread = input channel ch >= 1: its planes are added from the highest m down = ascending bin, two planes per trip (both
+    // fetched before either is added).  (Testing all 48 bins and adding under the test -- the first version -- made every wave walk 48
+    // dependent LDS round trips per channel: 27 k cycles of a 60 k-cycle workgroup.)
     const bool whole = x0 + 16 <= W;
-    for (int ch = tid; ch < nch; ch += PT_THREADS) {
+#pragma unroll
+    for (int k = 0; k < NCHI; ++k) {
+        const int ch = 1 + tid + k * PT_THREADS;
+        if (1 + k * PT_THREADS >= nch) break;                        // uniform
+        unsigned mask = cmask[k];
+        const float chf = (float)ch;
         f32x4 o[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        auto add = [&](int bin, int t) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(part + ((size_t)bin * nT + t) * 16);
+        const f32x4* zero4 = reinterpret_cast<const f32x4*>(part);   // (never added)
+        while (__any(mask != 0)) {
+            const int m1 = mask ? 32 - __builtin_clz(mask) : 0;
+            mask &= m1 ? ~(1u << (m1 - 1)) : 0u;
+            const int m2 = mask ? 32 - __builtin_clz(mask) : 0;
+            mask &= m2 ? ~(1u << (m2 - 1)) : 0u;
+            const int b1 = (int)(chf * __builtin_amdgcn_rcpf((float)(m1 ? m1 : 1)) + 0.25f), b2 = (int)(chf * __builtin_amdgcn_rcpf((float)(m2 ? m2 : 1)) + 0.25f);
+            const f32x4* p1 = m1 ? reinterpret_cast<const f32x4*>(part + ((size_t)b1 * nT + (m1 - 1)) * 16) : zero4;
+            const f32x4* p2 = m2 ? reinterpret_cast<const f32x4*>(part + ((size_t)b2 * nT + (m2 - 1)) * 16) : zero4;
+            const f32x4 v0 = p1[0], v1 = p1[1], v2 = p1[2], v3 = p1[3], w0 = p2[0], w1 = p2[1], w2 = p2[2], w3 = p2[3];
+            if (m1) { o[0] += v0; o[1] += v1; o[2] += v2; o[3] += v3; }
+            if (m2) { o[0] += w0; o[1] += w1; o[2] += w2; o[3] += w3; }
+        }
+        if (ch < nch) {
+            float* dst = gin + ((size_t)ch * H + y) * W + x0;
+            if (whole) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] += p[q];
-        };
-        if (ch == 0) {
-            for (int t = 0; t < nT; ++t) add(0, t);
-        } else {
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4u*>(dst + 4 * q) = o[q];
+            } else {
 #pragma unroll
-            for (int bin = 1; bin < KK; ++bin) {
-                const int q = ch / bin;                              // constant divisor: a multiply
-                if (q * bin == ch && q <= nT) add(bin, q - 1);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (x0 + 4 * q + r < W) dst[4 * q + r] = o[q][r];
             }
         }
-        float* dst = gin + ((size_t)ch * H + y) * W + x0;
-        if (whole) {
+    }
+    if (tid < 16 && x0 + tid < W) {                                  // channel 0: bin 0 of every target, ascending t; thread = column
+        float a = 0.f;
+        for (int t0 = 0; t0 < nT; t0 += 8) {
+            float v[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4u*>(dst + 4 * q) = o[q];
-        } else {
+            for (int k = 0; k < 8; ++k) v[k] = t0 + k < nT ? part[(size_t)(t0 + k) * 16 + tid] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (x0 + 4 * q + r < W) dst[4 * q + r] = o[q][r];
+            for (int k = 0; k < 8; ++k) a = t0 + k < nT ? a + v[k] : a;
         }
+        gin[(size_t)y * W + x0 + tid] = a;
     }
     D2T_KSTAMP(4);
 }
 
+static int ps_tiles_ec(int R, int nT)                                // hits per chunk: 32 where the LDS holds it
+{
+    return ps_tiles_lds(R, nT, 32) <= (size_t)LDS_MAX ? 32 : 16;
+}
+
 static bool psroipool_bwd_tiles_supported(int R, int nT, int H, int W, int k)
 {
-    return k == KT && R >= 1 && R <= PT_MAXR && nT >= 1 && nT <= 32 && H >= 1 && H <= 32767 && W >= 1 && W <= 127 &&
-           1LL * R * nT * KK * 4 < 0x7ffffff0LL && 1LL * nT * KK * H * W < 0x7fffffffLL && 1LL * H * ((W + 15) / 16) < 0x7fffffffLL &&
-           ps_tiles_lds(R, nT) <= (size_t)LDS_MAX;
+    return k == KT && R >= 1 && R <= PT_MAXR && nT >= 1 && nT <= 32 && H >= 1 && H <= 255 && W >= 1 && W <= 255 &&
+           1LL * R * nT * KK * 4 < 0x7ffffff0LL && 1LL * nT * KK * H * W < 0x7fffffffLL && ps_tiles_lds(R, nT, 16) <= (size_t)LDS_MAX;
 }
 
 static int psroipool_bwd_tiles_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, hipStream_t st)
 {
-    const int xtiles = (W + 15) / 16;
-    const size_t lds = ps_tiles_lds(R, nT);
-    if (nT <= 16) {
-        D2T_ENSURE_DYNAMIC_LDS(k_ps_bwd_tiles<1>, LDS_MAX);
-        hipLaunchKernelGGL(k_ps_bwd_tiles<1>, dim3(H * xtiles), dim3(PT_THREADS), lds, st, gout, rois, gin, R, nT, H, W, xtiles);
-    } else {
-        D2T_ENSURE_DYNAMIC_LDS(k_ps_bwd_tiles<2>, LDS_MAX);
-        hipLaunchKernelGGL(k_ps_bwd_tiles<2>, dim3(H * xtiles), dim3(PT_THREADS), lds, st, gout, rois, gin, R, nT, H, W, xtiles);
+    const int xtiles = (W + 15) / 16, ec = ps_tiles_ec(R, nT);
+    const size_t lds = ps_tiles_lds(R, nT, ec);
+#define D2T_LAUNCH_PT(NCTV, ECV)                                                                                                   \
+    {                                                                                                                              \
+        D2T_ENSURE_DYNAMIC_LDS((k_ps_bwd_tiles<NCTV, ECV>), LDS_MAX);                                                              \
+        hipLaunchKernelGGL((k_ps_bwd_tiles<NCTV, ECV>), dim3(H * xtiles), dim3(PT_THREADS), lds, st, gout, rois, gin, R, nT, H, W, xtiles); \
     }
+    if (nT <= 16) { if (ec == 32) D2T_LAUNCH_PT(1, 32) else D2T_LAUNCH_PT(1, 16) }
+    else { if (ec == 32) D2T_LAUNCH_PT(2, 32) else D2T_LAUNCH_PT(2, 16) }
+#undef D2T_LAUNCH_PT
     return launch_status();
 }
 
@@ -1793,7 +1842,6 @@ static int ps_bwd_design(int R, int nT, int H, int W, int k)
                tl = psroipool_bwd_tiles_supported(R, nT, H, W, k);
     const int f = ps_bwd_forced();
     if (f == 5 && tl) return 4;
-    if (f == 0 && tl) return 4;                                        // round 6: up to 1,024 RoIs, one launch, no workspace
     if (f == 4 && rw) return 3;
     if (f == 3 && g) return 2;
     if (f == 2 && s) return 1;

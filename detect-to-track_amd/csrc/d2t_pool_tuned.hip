@@ -352,7 +352,7 @@ extern "C" int d2t_lab_roipool_fwd_occupancy(int H, int W, int threads, int* blo
 bool roipool_fwd_supported(int R, int C, int H, int W, int k)
 {
     if (!(R >= 1 && C >= 1 && H >= 1 && W >= 1 && H <= 255 && W <= 255)) return false;
-    return k == KT ? sat_cg(C, H, W) > 0 : sat2_anyk(C, H, W, k);
+    return k == KT ? (roipool_fwd_direct_supported(R, C, H, W, k) || sat_cg(C, H, W) > 0) : sat2_anyk(C, H, W, k);
 }
 
 size_t roipool_fwd_ws_bytes(int, int, int, int, int) { return 0; }
@@ -360,6 +360,9 @@ size_t roipool_fwd_ws_bytes(int, int, int, int, int) { return 0; }
 int roipool_fwd_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, int k,
                     void*, hipStream_t st)
 {
+    // round 6: k = 7 in the reference's own order (d2t_roipool_fwd_direct.hip: bit-identical, no tables); scan builds: D2T_ROI_FWD=sat keeps the tables
+    if (k == KT && roipool_fwd_direct_supported(R, C, H, W, k) && lab_env_int("D2T_ROI_FWD_SAT", 0) == 0)
+        return roipool_fwd_direct_f32(fm, rois, out, R, C, H, W, st);
     const int CG = k == KT ? sat_cg(C, H, W) : 2;
     const SatLayout L = sat_layout(CG, H, W, k == KT || 4 * k < GEO8 ? GEO8 : 4 * k);
     const int gx = (C + CG - 1) / CG;

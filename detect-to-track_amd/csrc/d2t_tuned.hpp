@@ -35,6 +35,10 @@ size_t roipool_fwd_ws_bytes(int R, int C, int H, int W, int k);
 int    roipool_fwd_f32(const float* fm, const float* rois, float* out,
                        int R, int C, int H, int W, int k, void* ws, hipStream_t st);
 
+// d2t_roipool_fwd_direct.hip: k = 7 in the reference's order (bit-identical)
+bool   roipool_fwd_direct_supported(int R, int C, int H, int W, int k);
+int    roipool_fwd_direct_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, hipStream_t st);
+
 bool   roipool_bwd_supported(int R, int C, int H, int W, int k);
 size_t roipool_bwd_ws_bytes(int R, int C, int H, int W, int k);
 int    roipool_bwd_f32(const float* gout, const float* rois, float* gin,

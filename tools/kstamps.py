@@ -59,6 +59,13 @@ def main():
         run("d2t_lab_pool_fwd_stamps",
             lambda: bench_ops._check(lib.d2t_roipool_fwd_f32(fm.data_ptr(), rois.data_ptr(), out.data_ptr(), R, C, H, W, K, 0, 0, 0, st)),
             ["entry", "planes in LDS", "prefix2d done", "geometry 1 done", "look-ups 1 done", "geometry 2 done", "look-ups 2 done", "end"])
+    if what == "roipool_direct":                                     # round 6: d2t_roipool_fwd_direct.hip
+        R, C, H, W, K = [int(x) for x in sys.argv[2:6]] + [7] if len(sys.argv) > 5 else (300, 1024, 38, 63, 7)
+        fm, out = torch.rand(C, H, W, device=dev), torch.empty(R, C, K, K, device=dev)
+        rois = torch.from_numpy(bench_ops.random_rois(R, 0)).to(dev)
+        run("d2t_lab_roipool_direct_stamps",
+            lambda: bench_ops._check(lib.d2t_roipool_fwd_f32(fm.data_ptr(), rois.data_ptr(), out.data_ptr(), R, C, H, W, K, 0, 0, 0, st)),
+            ["entry", "planes + geometry in LDS", "bins walked, stored"])
     if what == "roipool_bwd":
         R, C, H, W, K = 300, 1024, 38, 63, 7
         go, gin = torch.rand(R, C, K, K, device=dev), torch.empty(C, H, W, device=dev)
