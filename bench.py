@@ -384,7 +384,7 @@ def run(args, device):
     # its steps gets (no event records, no host work between the kernels).  The C-ABI calls are asynchronous, allocate
     # nothing and keep no state, so they capture; the replay is checked bit for bit against eager launches.  (Per-kernel
     # events cannot be recorded inside a captured graph on this stack: torch refuses external events on ROCm and
-    # hipEventRecordWithFlags(..., hipEventRecordExternal) returns hipErrorInvalidValue, tools/r3_extev.py.)
+    # hipEventRecordWithFlags(..., hipEventRecordExternal) returns hipErrorInvalidValue, lab/tools/r3_extev.py.)
     graph_replay = None
     if args.graph and hasattr(device, "capture"):
         graph, err = None, None
@@ -489,7 +489,7 @@ def run(args, device):
             k["mfma"]["frac_launch"] = k["mfma"]["frac"] * k["us"] / k["us_minus_record_overhead"]
             k["hbm"]["frac_launch"] = k["hbm"]["frac"] * k["us"] / k["us_minus_record_overhead"]
         # Third roof: the L1 / texture-address line rate.  lines = cache-line (tag) accesses per launch
-        # (TCP_TOTAL_CACHE_ACCESSES, PMC pass of the same command), peak = the chip-wide rate csrc/lab/ta_lab sustains with
+        # (TCP_TOTAL_CACHE_ACCESSES, PMC pass of the same command), peak = the chip-wide rate lab/csrc/ta_lab sustains with
         # every CU streaming whole lines; both from profiles/ta_roof.json, the duration measured here.
         ta = None
         tafile = ROOT / "profiles" / "ta_roof.json"

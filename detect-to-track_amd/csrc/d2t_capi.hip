@@ -6,7 +6,7 @@
 #include "d2t_kernels.hpp"
 #include "d2t_tuned.hpp"
 #ifdef D2T_LAB_KERNELS
-#include "lab/d2t_lab_selectors.h"
+#include "../../lab/csrc/d2t_lab_selectors.h"
 #endif
 
 using namespace d2t;
@@ -43,7 +43,7 @@ int check_pool(const void* fm, const void* rois, const void* out, int R, int C, 
 }
 
 // The four selectors of include/d2t_ops.h.  Values 3, 4, 6, 7 named lab kernels in ABI 1.05; the product library rejects them
-// since 1.06 -- they exist in the lab build only (make lab: -DD2T_LAB_KERNELS, csrc/lab/d2t_lab_selectors.h).
+// since 1.06 -- they exist in the lab build only (make lab: -DD2T_LAB_KERNELS, lab/csrc/d2t_lab_selectors.h).
 #ifdef D2T_LAB_KERNELS
 inline bool impl_ok(int impl) { return impl >= D2T_IMPL_AUTO && impl <= D2T_LAB_IMPL_STRIP4; }
 // backward kernel of the tuned path: 0 the product's, 1 the 16-wave strip kernel, 3 bf16x3, 4 strips 8 pixels wide, 5 strips 4 pixels wide
@@ -71,7 +71,7 @@ static inline bool ws_misaligned_(const void* ws, size_t ws_bytes) { return ws &
 int d2t_version(void) { return 106; }   // 1.06: round 5 -- selectors trimmed to AUTO / GENERIC / MFMA / FAST (3, 4, 6, 7 are rejected: lab build only); band-split forward for small grids
 
 #ifdef D2T_LAB_KERNELS
-int d2t_lab_build(void) { return 1; }   // present in the lab build only (csrc/lab/d2t_lab_selectors.h)
+int d2t_lab_build(void) { return 1; }   // present in the lab build only (lab/csrc/d2t_lab_selectors.h)
 #endif
 
 const char* d2t_error_string(int code)

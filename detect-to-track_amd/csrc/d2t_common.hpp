@@ -120,7 +120,7 @@ inline int lab_env_int(const char*, int dflt) { return dflt; }
 inline const char* lab_env_str(const char*) { return nullptr; }
 #endif
 
-// In-kernel clock reads of knob builds (-DD2T_ENV_KNOBS; tools/kstamps.py): [workgroup][16] s_memtime values of thread 0.  A translation
+// In-kernel clock reads of knob builds (-DD2T_ENV_KNOBS; lab/tools/kstamps.py): [workgroup][16] s_memtime values of thread 0.  A translation
 // unit that stamps says D2T_KSTAMP_DEFINE(setter) once (the library is built without relocatable device code: the pointer is per unit) and
 // D2T_KSTAMP(i) where it wants a clock read.  The product library is built without D2T_ENV_KNOBS: no stamp executes there.
 #ifdef D2T_ENV_KNOBS

@@ -30,7 +30,7 @@
 
 namespace d2t { namespace tuned {
 
-// Per-wave clock reads for the developer harness csrc/lab/bwd8_stamp_lab.hip (a separate diagnostic build, see the
+// Per-wave clock reads for the developer harness lab/csrc/bwd8_stamp_lab.hip (a separate diagnostic build, see the
 // MI355X guide "In-kernel stamps"); the product library is built without D2T_LAB: no stamp executes there.
 #ifdef D2T_LAB
 __device__ unsigned long long* lab8_stamps;                         // [workgroup][wave][16]
@@ -150,7 +150,7 @@ typedef std::integral_constant<int, 5> I5;
 #ifndef S8_ABL
 #define S8_ABL 0      // timing ablations (lab builds only, results are wrong): 1 no S reloads, 2 no tile stores, 4 no G loads, 8 no ring writes, 32 role 0 alone, 64 role 1 alone
 #endif
-template <int role, int S8_CT, bool ROWKB, int ABL = 0, bool FLEX = false>    // ABL: ablation mask of csrc/lab/bwd8_stamp_lab (timing only)
+template <int role, int S8_CT, bool ROWKB, int ABL = 0, bool FLEX = false>    // ABL: ablation mask of lab/csrc/bwd8_stamp_lab (timing only)
 __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const float* __restrict__ gout,
                                             const float* __restrict__ fm0, const float* __restrict__ fm1,
                                             float* __restrict__ g0, float* __restrict__ g1,
@@ -340,7 +340,7 @@ __device__ __forceinline__ void strip8_body(float (&ring)[2][S8_RING], const flo
             // The super-step's non-MFMA work: tile store (k-block 0), ring writes of G(ss+1) (1), requests for G(ss+2) (2).
             // (Measured and dropped: placing it behind the 40th MFMA for waves 4-7 so that the two waves of a SIMD never
             // sit in it together -- no change, 72.1 us either way: the cost of these memory instructions is their wait
-            // for the texture-address unit, csrc/lab/ta_lab, not the coincidence.)
+            // for the texture-address unit, lab/csrc/ta_lab, not the coincidence.)
             auto slice = [&]() {
                 if (q <= 2) D2T_WCLK(w_a);
                 if (q == 0) {                                        // complete since the end of the previous super-step

@@ -14,7 +14,7 @@
 // a band-set needs only its own 4 / 7 window rows, and TW is chosen so that the grid is ONE workgroup per CU (38 x 63:
 // TW 4 -> 240 workgroups; 38 x 75: TW 5 -> 240).
 //
-// What the in-kernel clocks said on the way (tools/band_stamps.py, profiles/r05_*_band_stamps.txt):
+// What the in-kernel clocks said on the way (lab/tools/band_stamps.py, profiles/r05_*_band_stamps.txt):
 //   * the CU's address unit takes ~55 cycles per LDS-DMA instruction of 64 x 16 bytes whatever wave issues it, and a
 //     wave that waits to issue one issues no MFMA: with the DMA dealt to the computing waves a chunk took 0.61 us
 //     where the matrix work is 0.43 us.  So WL dedicated LOADER waves issue every DMA instruction; the computing
@@ -37,7 +37,7 @@
 namespace d2t { namespace tuned {
 
 #ifdef D2T_BAND_STAMPS
-// in-kernel stamps of the stamp build (-DD2T_ENV_KNOBS -DD2T_BAND_STAMPS) (tools/band_scan.py --stamps): [workgroup][16] clock reads of compute wave 0 (0-4) and of the first
+// in-kernel stamps of the stamp build (-DD2T_ENV_KNOBS -DD2T_BAND_STAMPS) (lab/tools/band_scan.py --stamps): [workgroup][16] clock reads of compute wave 0 (0-4) and of the first
 // loader wave (8-13), s_memrealtime at entry / exit (14, 15).  The product library is built without D2T_ENV_KNOBS: no stamp executes there.
 __device__ unsigned long long* band_stamps;
 __device__ int band_dbg;                          // ablation bits: 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads, 8 no stores
@@ -452,7 +452,7 @@ int corr_fwd_band_config(int B, int H, int W)
     const long long tasks = 6LL * B * tiles_i * tiles_j;
     if (tasks > 2600) {
         // Medium grids (B = 3 .. 5 at the model's maps: too few 5-tile segments for k_corr_fwd_seg, several rounds of band workgroups).
-        // tools/band_scan.py, us, two-tile segments -> band: B 4 C 256 38 x 63 51 -> 33 (TW 4 x NB 2: 480 workgroups of 8 + 4 waves, two
+        // lab/tools/band_scan.py, us, two-tile segments -> band: B 4 C 256 38 x 63 51 -> 33 (TW 4 x NB 2: 480 workgroups of 8 + 4 waves, two
         // per CU), B 3 C 1024 38 x 75 161 -> 98 (NB 2), B 5 C 256 38 x 63 52 -> 44 and B 5 C 1024 38 x 75 171 -> 151 (NB 1; NB 2 loses there).
         const long long n42 = 3LL * B * tiles_i * ((tiles_j + 3) / 4);
         return n42 > 400 && n42 <= 512 ? 142 : 141;
@@ -474,7 +474,7 @@ int corr_fwd_band_f32(int cfg, int nl, const float* const* fm0, const float* con
         D2T_BAND_CASE(141, 4, 1, 1, 16, 3, 4)
         D2T_BAND_CASE(1251, 5, 1, 2, 16, 3, 6)
         D2T_BAND_CASE(142, 4, 2, 1, 16, 3, 4)
-#ifdef D2T_ENV_KNOBS                                                  /* scan builds (tools/band_scan.py) */
+#ifdef D2T_ENV_KNOBS                                                  /* scan builds (lab/tools/band_scan.py) */
         D2T_BAND_CASE(1141, 4, 1, 1, 16, 3, 8)
         D2T_BAND_CASE(151, 5, 1, 1, 16, 3, 4)
         D2T_BAND_CASE(251, 5, 1, 2, 16, 3, 4)

@@ -30,7 +30,7 @@
 
 namespace d2t { namespace tuned {
 
-// In-kernel stamps for the developer harness csrc/lab/fwd_lab.hip (a separate diagnostic build, see
+// In-kernel stamps for the developer harness lab/csrc/fwd_lab.hip (a separate diagnostic build, see
 // the MI355X guide "In-kernel stamps").  The product library is built without D2T_LAB: no stamp
 // executes there.
 #ifdef D2T_LAB
@@ -51,7 +51,7 @@ __device__ unsigned long long* lab_stamps;                          // [workgrou
             lab_stamps[blockIdx.x * 32 + (i)] = t_;                                                   \
         }                                                                                             \
     } while (0)
-// per-wave clock reads for the backward strip kernel (csrc/lab/bwd_stamp_lab.hip); D2T_ABL: ablation mask of that lab
+// per-wave clock reads for the backward strip kernel (lab/csrc/bwd_stamp_lab.hip); D2T_ABL: ablation mask of that lab
 #ifndef D2T_ABL
 #define D2T_ABL 0
 #endif
@@ -133,7 +133,7 @@ static_assert(SG_KC * 4 * SG_NU % 64 == 0 && SG_MAXDMA <= SG_KC / 4, "DMA plan")
 // loads retire in order and a wave issues the same number (nd) for every chunk, so `vmcnt(nd)` at that
 // barrier means "my part of chunk ch+1 has landed" (chunk ch+2's may be in flight).
 //
-// DMA instructions are the expensive part of the loop (measured with csrc/lab/fwd_lab: removing them
+// DMA instructions are the expensive part of the loop (measured with lab/csrc/fwd_lab: removing them
 // takes 12 k cycles off a 67 k-cycle loop, ~50 cycles of SIMD issue each), so there are as few as the
 // bytes allow: the image pitch is the segment's own row count (27 rows at 38-row maps, not the
 // 35-row maximum), instructions are dealt round-robin to the waves, none is a parked dummy.
@@ -277,7 +277,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
         if (k >= nd) return;                                         // wave-uniform
         // Chunks are staged in ascending order, each of this wave's instructions once per chunk: its lane offset is ADVANCED by a chunk after
         // use (parked pieces stay out of range, see dv above) -- one v_add per DMA instruction, no select.  The f32 MFMA and
-        // the vector ALU do not overlap on a SIMD (csrc/lab/mfma_valu_lab: their times add), so a vector instruction in this loop is matrix time.
+        // the vector ALU do not overlap on a SIMD (lab/csrc/mfma_valu_lab: their times add), so a vector instruction in this loop is matrix time.
         // (The chunk base in a per-chunk DESCRIPTOR would need none, but hipcc then rebuilds the descriptor behind a waterfall loop.)
         (void)chunk;
         const int v = (int)dv[k];                                    // the instruction's voffset is unsigned in hardware
@@ -351,7 +351,7 @@ seg_body(const float* __restrict__ fm0b, const float* __restrict__ fm1b, float* 
     (void)dma_pos;
     // BPLC: the FM1 image's plane pitch as a compile-time constant (0: the run-time value).  With the pitch in the template the k-step
     // stride of the fragment reads is an immediate of the ds_read: one address per chunk and fragment instead of one per k-step.  (A vector
-    // instruction is matrix time on this chip -- csrc/lab/mfma_valu_lab.  Unrolling the loop over the three ring slots as well, so that no
+    // instruction is matrix time on this chip -- lab/csrc/mfma_valu_lab.  Unrolling the loop over the three ring slots as well, so that no
     // address is computed in it at all, ran out of registers: 128 VGPRs + 45 spilled SGPRs.)
     auto run = [&](auto nt_c, auto bpl_c) {
         constexpr int NT = decltype(nt_c)::value;                    // tasks of this wave: 0, 1 or 2
@@ -558,7 +558,7 @@ k_corr_fwd_seg(const float* __restrict__ fm0, const float* __restrict__ fm1, flo
 // Forward, channel-split ("split-K").  The real model correlates B = 1 pairs with 512 / 1024 / 2048 channels
 // (correlation_tracker.py:68-70): 38 five-tile segments for 256 CUs, and one-tile workgroups (190 of them) are bound
 // by the texture-address unit -- a 19 x 20 window per tile is 2.9x the cache lines per tile of a five-tile segment
-// (csrc/lab/ta_lab: ~2 cycles per 64-byte line touched).  So the channels of a level are split over S workgroups per
+// (lab/csrc/ta_lab: ~2 cycles per 64-byte line touched).  So the channels of a level are split over S workgroups per
 // segment: each runs the five-tile kernel body over its channel range and writes a partial-sum plane (reference
 // layout) into the workspace; k_corr_fwd_combine adds the S planes of every cell in ascending split order --
 // deterministic, no atomics -- and writes the caller's layout.  The sum is associated differently from the
@@ -663,7 +663,7 @@ k_corr_fwd_combine(CombineLevels lv, int B, int HW, CellLayout lay)
 }
 
 #ifdef D2T_ENV_KNOBS
-#include "lab/d2t_corr_fwd_segx.inc"       // scan builds only: the one- / two-tile forward the band-split kernel replaced
+#include "../../lab/csrc/d2t_corr_fwd_segx.inc"       // scan builds only: the one- / two-tile forward the band-split kernel replaced
 #endif
 
 bool corr_fwd_supported(int B, int C, int H, int W, int d, int s)
@@ -729,7 +729,7 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
     const int nseg = (tiles_i + SG_NU - 1) / SG_NU;
     const long long strip_blocks = 1LL * B * tiles_j * nseg;
 #ifdef D2T_ENV_KNOBS
-    if (lab_env_int("D2T_BAND_CFG", -1) > 0) {       // scan builds: the band-split kernel on any grid (tools/band_scan.py)
+    if (lab_env_int("D2T_BAND_CFG", -1) > 0) {       // scan builds: the band-split kernel on any grid (lab/tools/band_scan.py)
         if (lab_env_int("D2T_BAND_LEVEL_LAUNCHES", 0)) {                 // A/B: one launch per level
             for (int l = 0; l < nl; ++l) {
                 const int rc = corr_fwd_band_f32(lab_env_int("D2T_BAND_CFG", -1), 1, fm0 + l, fm1 + l, out + l, C + l, B, H, W, lay, st);
@@ -792,11 +792,11 @@ int corr_fwd_levels_f32(int nl, const float* const* fm0, const float* const* fm1
         for (int b2 = a + 1; b2 < nl; ++b2)
             if (C[order[b2]] > C[order[a]]) { const int t = order[a]; order[a] = order[b2]; order[b2] = t; }
     const bool two = 1LL * B * tiles_j * ((tiles_i + 1) / 2) >= 160;   // medium grids: segments of 2 p-tiles (B = 2, 38 x 63 / 75, C = 2048:
-                                                                        // 160 us against 181 us with one-tile workgroups, tools/levels_cost.py)
+                                                                        // 160 us against 181 us with one-tile workgroups, lab/tools/levels_cost.py)
     const int ns = two ? (tiles_i + 1) / 2 : tiles_i;
     const int per_level = B * tiles_j * ns;
     // One launch per level (D2T_EXP_LEVEL_LAUNCHES 0: all levels in one launch).  The tracker's three B = 1 levels are 190 one-tile
-    // workgroups each, one per CU by LDS: three launches 179 us, one 570-workgroup launch 273 us (tools/levels_cost.py) -- the
+    // workgroups each, one per CU by LDS: three launches 179 us, one 570-workgroup launch 273 us (lab/tools/levels_cost.py) -- the
     // heavy level's workgroups queue behind the light ones'.
 #ifndef D2T_EXP_LEVEL_LAUNCHES
 #define D2T_EXP_LEVEL_LAUNCHES 1
@@ -834,7 +834,7 @@ int corr_fwd_f32(const float* fm0, const float* fm1, float* out, int B, int C, i
 // strip kernels live in lab/d2t_corr_bwd16.inc and are compiled into the lab build only.
 // ====================================================================================
 #ifdef D2T_LAB_KERNELS
-#include "lab/d2t_corr_bwd16.inc"
+#include "../../lab/csrc/d2t_corr_bwd16.inc"
 #endif
 
 // The tuned backward = the 8-wave strip kernel: d_max 8, stride 1, maps at least 17 rows high (five 4-row tiles alive at a time).

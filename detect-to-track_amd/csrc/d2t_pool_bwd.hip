@@ -1178,7 +1178,7 @@ static int psroipool_bwd_gemm_f32(const float* gout, const float* rois, float* g
 // Every plane row is written once as an ascending-RoI chain fma(gradOut, 1 / n, acc): deterministic; <= 1 ulp per term from the
 // reference's gradOut / n (its atomics leave the order open).
 // Measured (bench_ops.py, us; the four-launch GEMM in brackets): R = 300 nT = 21: 25 (31); R = 300 nT = 31: 32 (41); R = 3000 nT = 4: 38
-// (59); R = 3000 nT = 31: 87 (71) -- there the dispatch keeps the GEMM.  Where a task's time goes (tools/kstamps.py,
+// (59); R = 3000 nT = 31: 87 (71) -- there the dispatch keeps the GEMM.  Where a task's time goes (lab/tools/kstamps.py,
 // profiles/r05_c_kstamps_ps_rows_*.txt, R = 3000 nT = 31, 130 k cycles): the k-steps 59 k (740 cycles each: a cell is ~4 columns wide,
 // an MFMA column tile 16, and 7 waves share 4 matrix pipes), issuing the run loads 37 k (a wave pays ~20 cycles per line its
 // instruction touches, and every (hit, target) run is its own line), the hit list 11 k.  Measured and dropped: the accumulation as an
@@ -1341,7 +1341,7 @@ k_ps_bwd_rows(const float* __restrict__ gout, const float* __restrict__ rois, fl
             };
             // one k-step: the lane's membership test is (unsigned)(column - first column) < width (false for every column of a width-0 entry),
             // the scale sits in the B operand; the tile mask of the k-step is the OR of its four entries' masks, read across the lane groups
-            // as scalars -- no vector instruction.  (Vector instructions are matrix time here: csrc/lab/mfma_valu_lab.)
+            // as scalars -- no vector instruction.  (Vector instructions are matrix time here: lab/csrc/mfma_valu_lab.)
             auto kstep = [&](const KOp& o) {
                 const int d0 = n - (o.jb & 0xff);
                 const unsigned wd = ((unsigned)o.jb >> 8) & 0xffu;
@@ -1414,7 +1414,7 @@ static bool psroipool_bwd_rows_supported(int R, int nT, int H, int W, int k)
 }
 
 // RoI ranges per task.  Every workgroup pays ~20 k cycles whatever it walks (hit scan, first chunk, plane stores) and two fit a CU, so
-// a range only pays where a task's walk is long: thousands of RoIs.  tools/ps_segs_scan.py, 38 x 75, us by ranges 1 / 2 / 3 / 4 (scan
+// a range only pays where a task's walk is long: thousands of RoIs.  lab/tools/ps_segs_scan.py, 38 x 75, us by ranges 1 / 2 / 3 / 4 (scan
 // build): R 3000 nT 4  58 / 44 / 51 / 49, nT 8  60 / 47 / 55 / 55, nT 16  66 / 52 / 65 / 64, nT 31  87 / 93 / 114 / 114;
 // R 1000 nT 4  27 / 25 / 31 / 33, nT 16  35 / 36 / 44 / 49; R 300 nT 21  31 / 41 / 51 / 63 (profiles/r05_e_ps_rows_roi_ranges.txt).
 static int ps_rows_segs(int R, int nT)
@@ -1450,374 +1450,21 @@ static int psroipool_bwd_rows_f32(const float* gout, const float* rois, float* g
     return launch_status();
 }
 
-// ---------------------------------------------------------------------------------------
-// PSROIPool backward, TILE form (round 6): ONE launch, no partial planes in memory, no workspace.  The row form above writes a plane
-// per (target, bin) and a second launch adds the planes of every input channel ((t+1) * bin is many-to-one, ps_roipool_cuda.cu:58:
-// at 21 targets 812 of the 1,029 (target, bin) pairs share their channel with another pair and 581 channels have no pair at all) --
-// 3.7-4.7x the op's bytes through HBM and two dependent small launches.  Here a workgroup owns (map row y, 16 map columns) and ALL 49
-// bins: the planes it would have written are 49 x nT x 16 floats and stay in LDS; its last phase adds them per input channel and
-// writes every channel's 64-byte run of gradIn once (zeros included).
-//   1. thread = RoI: the row / column bounds of its 7 + 7 bin rows / columns (bin_axis, as everywhere) -> an LDS table; wave i then
-//      lists the RoIs whose bin row i holds y and whose cells reach the tile's columns: one list, ordered by bin row then RoI, every bin
-//      row's run padded to whole k-steps of 4;
-//   2. chunks of the list: the hits' runs gradOut[r][t][i][0..6] -> LDS as A[j][hit][target] (two 16-byte loads per run, two chunks in
-//      flight), wave j multiplies D_(i,j)[t][x] += A[t][hit] * (x in cell ? 1 / n : 0) on the f32 matrix pipe; when the list moves on
-//      to the next bin row the wave's tile goes to the LDS planes;
-//   3. thread = input channel: which targets feed it (t + 1 divides ch, ch / (t + 1) <= 48) as a bit mask, then its planes in ascending
-//      bin order (the order of k_psroipool_bwd_gather), 16 columns stored.
-// Deterministic (fixed order, no atomics); <= 1 ulp per term from the reference's gradOut / n like the row form.
-// At most PT_MAXR RoIs (list entry = RoI | bin row << 10), maps up to 255 x 255, what fits the LDS; larger calls keep the row / GEMM forms.
-// ---------------------------------------------------------------------------------------
-constexpr int PT_THREADS = KT * 64;                                  // 448: wave j = bin column j (phase 2), wave i = bin row i (phase 1)
-constexpr int PT_MAXR = 1024;
-constexpr int PT_PASSES = (PT_MAXR + PT_THREADS - 1) / PT_THREADS;   // 3 RoIs per thread at most
-
-static size_t ps_tiles_lds(int R, int nT, int ec)
-{
-    const int tp = nT <= 16 ? 16 : 32;
-    const size_t part = (size_t)KK * nT * 16 * 4, a = 2ull * KT * ec * tp * 4, e = 2ull * ec * 8 * 8, misc = 256,
-                 geo = (size_t)R * 32, list = (((size_t)KT * R + 4 * KT + 7) & ~(size_t)7) * 2;
-    return part + a + e + misc + geo + list;
-}
-
-template <int NCT, int EC>
-__global__ void __launch_bounds__(PT_THREADS)
-k_ps_bwd_tiles(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gin, int R, int nT, int H, int W, int xtiles)
-{
-    constexpr int TP = 16 * NCT;                                     // padded targets
-    extern __shared__ __attribute__((aligned(16))) float ptl[];
-    float* part = ptl;                                               // [49][nT][16]
-    float (*A)[KT][EC][TP] = reinterpret_cast<float (*)[KT][EC][TP]>(part + (size_t)KK * nT * 16);          // [2]
-    int (*ejb)[EC][8] = reinterpret_cast<int (*)[EC][8]>(reinterpret_cast<float*>(A) + 2 * KT * EC * TP);  // [2]
-    float (*esc)[EC][8] = reinterpret_cast<float (*)[EC][8]>(reinterpret_cast<int*>(ejb) + 2 * EC * 8);    // [2]
-    int* misc = reinterpret_cast<int*>(esc) + 2 * EC * 8;            // [0..6] hits per bin row, [8..14] run starts, [15] list length
-    unsigned short* geo = reinterpret_cast<unsigned short*>(misc + 64);   // [R][16]: row bounds of i (lo | hi << 8), column bounds of j, reaches-the-tile
-    unsigned short* list = geo + (size_t)R * 16;
-
-    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = wave;
-    // an XCD takes a contiguous run of (row, column tile): the gradOut runs of a RoI are read by the workgroups of the ~3 rows x ~2
-    // tiles it covers -- one L2 fetches them once
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-    const int id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int y = id / xtiles, xt = id - y * xtiles, x0 = 16 * xt;
-    D2T_KSTAMP(0);
-
-    // ---- 1a. thread = RoI: geometry table (the loads go out first, the planes are zeroed under their latency)
-    f32x4 ro[PT_PASSES];
-#pragma unroll
-    for (int ps = 0; ps < PT_PASSES; ++ps) {
-        const int r = ps * PT_THREADS + tid;
-        ro[ps] = r < R ? f32x4(*reinterpret_cast<const f32x4u*>(rois + 4 * (size_t)r)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    {
-        f32x4* p4 = reinterpret_cast<f32x4*>(part);                  // a bin no hit reaches keeps its zeros
-        const int n4 = KK * nT * 4;
-        for (int e = tid; e < n4; e += PT_THREADS) p4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int ps = 0; ps < PT_PASSES; ++ps) {
-        const int r = ps * PT_THREADS + tid;
-        if (r >= R) continue;
-        unsigned gq[8];
-        bool reach = false;
-        unsigned cb[KT], rb[KT];
-#pragma unroll
-        for (int q = 0; q < KT; ++q) {
-            int b0, b1;
-            bin_axis<float>(ro[ps][1] - ro[ps][3] / 2.0f, ro[ps][3] / static_cast<float>(KT), q, W, b0, b1);
-            reach = reach || (b1 > b0 && b0 < x0 + 16 && b1 > x0);
-            cb[q] = (unsigned)b0 | ((unsigned)b1 << 8);
-        }
-#pragma unroll
-        for (int i = 0; i < KT; ++i) {
-            int a0 = 0, a1 = 0;
-            if (reach) bin_axis<float>(ro[ps][0] - ro[ps][2] / 2.0f, ro[ps][2] / static_cast<float>(KT), i, H, a0, a1);
-            rb[i] = (unsigned)a0 | ((unsigned)a1 << 8);
-        }
-        gq[0] = rb[0] | (rb[1] << 16); gq[1] = rb[2] | (rb[3] << 16); gq[2] = rb[4] | (rb[5] << 16); gq[3] = rb[6] | (cb[0] << 16);
-        gq[4] = cb[1] | (cb[2] << 16); gq[5] = cb[3] | (cb[4] << 16); gq[6] = cb[5] | (cb[6] << 16); gq[7] = reach ? 1u : 0u;
-        u32x4* gp = reinterpret_cast<u32x4*>(geo + (size_t)r * 16);
-        gp[0] = u32x4{gq[0], gq[1], gq[2], gq[3]};
-        gp[1] = u32x4{gq[4], gq[5], gq[6], gq[7]};
-    }
-    __syncthreads();
-    // ---- 1b. wave i: the RoIs whose bin row i holds y (and that reach the tile), ascending; bit `it` of mybits = RoI 64 it + lane is one
-    const int i_w = wave, nit = (R + 63) >> 6;                       // <= 16 iterations
-    unsigned mybits = 0;
-    int mycount = 0;
-    for (int it = 0; it < nit; ++it) {
-        const int r = 64 * it + lane;
-        bool in = false;
-        if (r < R) {
-            const unsigned rbv = geo[(size_t)r * 16 + i_w];
-            in = geo[(size_t)r * 16 + 14] != 0 && y >= (int)(rbv & 255u) && y < (int)(rbv >> 8);
-        }
-        mybits |= in ? 1u << it : 0u;
-        mycount += __builtin_popcountll(__ballot(in));
-    }
-    if (lane == 0) misc[i_w] = mycount;
-    __syncthreads();
-    int start = 0, total = 0;                                        // this wave's run in the list; the padded length of the list
-#pragma unroll
-    for (int i = 0; i < KT; ++i) {
-        const int c = misc[i], pad = (c + 3) & ~3;
-        start = i == i_w ? total : start;
-        total += pad;
-    }
-    {
-        int pos = start;
-        for (int it = 0; it < nit; ++it) {
-            const bool in = (mybits >> it) & 1u;
-            const unsigned long long mk = __ballot(in);
-            if (in) list[pos + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (unsigned short)((64 * it + lane) | (i_w << 10));
-            pos += __builtin_popcountll(mk);
-        }
-        if (lane < ((mycount + 3) & ~3) - mycount) list[pos + lane] = 0xffffu;   // padding entries: no RoI
-    }
-    __syncthreads();
-    D2T_KSTAMP(1);
-
-    // ---- 2. chunks of EC list entries
-    const unsigned gout_bytes = (unsigned)((size_t)R * nT * KK * 4);
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, gout_bytes, 0x00020000);
-    const int nchunk = (total + EC - 1) / EC;
-    constexpr int NLD = (2 * EC * TP + PT_THREADS - 1) / PT_THREADS;  // loads of 16 bytes per thread and chunk
-    struct Stage { f32x4 run[NLD]; int gjb; float gsc; };
-    auto load_chunk = [&](Stage& sg, int c) {                        // global -> registers
-        const int e0 = c * EC;
-        sg.gjb = 0; sg.gsc = 0.f;
-        if (tid < EC * KT) {
-            const int e = tid / KT, q = tid - e * KT;
-            const int ent = e0 + e < total ? list[e0 + e] : 0xffff;
-            if (ent != 0xffff) {
-                const int r = ent & 1023, i = ent >> 10;
-                const unsigned rbv = geo[(size_t)r * 16 + i], cbv = geo[(size_t)r * 16 + 7 + q];
-                const int a0 = rbv & 255u, a1 = rbv >> 8, b0 = cbv & 255u, b1 = cbv >> 8;
-                const int hh = a1 - a0, ww = b1 - b0;
-                const bool any = hh > 0 && ww > 0 && b0 < x0 + 16 && b1 > x0;
-                // first column relative to the tile (+256) | width << 9 | reaches the tile << 17 | bin row << 24 (always: the k-step's bin row is read from it)
-                sg.gjb = (i << 24) | (any ? (b0 - x0 + 256) | (ww << 9) | (1 << 17) : 0);
-                sg.gsc = any ? 1.0f / static_cast<float>(hh * ww) : 0.f;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int sl = tid + k * PT_THREADS, rn = sl >> 1, half = sl & 1, e = rn / TP, t = rn - e * TP;
-            const int ent = rn < EC * TP && e0 + e < total ? list[e0 + e] : 0xffff;
-            const bool on = ent != 0xffff && t < nT;
-            const int off = on ? (((ent & 1023) * nT + t) * KK + (ent >> 10) * KT) * 4 + 12 * half : 0x7ffffff0;   // out of range: zeros
-            sg.run[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
-        }
-    };
-    auto store_chunk = [&](const Stage& sg, int buf) {               // registers -> LDS
-        if (tid < EC * KT) {
-            const int e = tid / KT, q = tid - e * KT;
-            ejb[buf][e][q] = sg.gjb; esc[buf][e][q] = sg.gsc;
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int sl = tid + k * PT_THREADS, rn = sl >> 1, half = sl & 1, e = rn / TP, t = rn - e * TP;
-            if (rn < EC * TP) {
-                if (half == 0) { A[buf][0][e][t] = sg.run[k][0]; A[buf][1][e][t] = sg.run[k][1]; A[buf][2][e][t] = sg.run[k][2]; A[buf][3][e][t] = sg.run[k][3]; }
-                else { A[buf][4][e][t] = sg.run[k][1]; A[buf][5][e][t] = sg.run[k][2]; A[buf][6][e][t] = sg.run[k][3]; }
-            }
-        }
-    };
-    f32x4 acc[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int i_acc = -1;                                                  // bin row the accumulators belong to (wave-uniform)
-    auto flush = [&]() {                                             // D[m = target 16 ct + 4 g + r][column n] -> the LDS plane of bin (i_acc, j)
-        if (i_acc < 0) return;
-        const int bin = i_acc * KT + j;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const f32x4 v = acc[ct];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = 16 * ct + 4 * g + r;
-                if (t < nT) part[((size_t)bin * nT + t) * 16 + n] = v[r];
-            }
-            // Cold path, as in the row form: a non-finite gradOut value times a 0 weight poisons columns outside its cell (the reference,
-            // ps_roipool_cuda.cu:131-139, only adds to the cell's own pixels); the wave recomputes the tile with exact membership.
-            if (__builtin_expect(__any(pool_nonfinite4(v)), 0)) {
-                for (int e = lane; e < 256; e += 64) {
-                    const int t = 16 * ct + (e >> 4), xx = x0 + (e & 15);
-                    if (t >= nT) continue;
-                    float a = 0.f;
-                    for (int r = 0; r < R; ++r) {
-                        const Bounds cb = psroi_cell<float>(rois + 4 * (size_t)r, i_acc, j, H, W, KT);
-                        const int nn = (cb.i1 - cb.i0) * (cb.j1 - cb.j0);
-                        if (y >= cb.i0 && y < cb.i1 && xx >= cb.j0 && xx < cb.j1)
-                            a = __builtin_fmaf(gout[((size_t)r * nT + t) * KK + bin], 1.0f / static_cast<float>(nn), a);
-                    }
-                    part[((size_t)bin * nT + t) * 16 + (e & 15)] = a;
-                }
-            }
-            acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    Stage sa, sb;                                                    // two chunks in flight: chunk c+2 is requested before the MFMAs of chunk c
-    if (nchunk > 0) load_chunk(sa, 0);
-    // Phase 3's bookkeeping, under the latency of the first loads: thread = input channel ch = 1 + tid + 448 k; bit m-1 of cmask[k] = target
-    // m-1 feeds it through bin ch / m (m divides ch, ch / m <= 48).
-    const int nch = nT * KK;
-    constexpr int NCHI = (32 * KK + PT_THREADS - 1) / PT_THREADS;    // 4 channels per thread at most
-    unsigned cmask[NCHI];
-#pragma unroll
-    for (int k = 0; k < NCHI; ++k) {
-        const int ch = 1 + tid + k * PT_THREADS;
-        cmask[k] = 0;
-        if (ch < nch) {
-            const float chf = (float)ch;
-#pragma unroll
-            for (int m = 1; m <= TP; ++m) {
-                const int q = (int)(chf * (1.0f / (float)m) + 0.25f);    // ch / m where m divides ch (ch < 2^11: the product is off by < 1e-3)
-                cmask[k] |= (m <= nT && q * m == ch && q < KK) ? 1u << (m - 1) : 0u;
-            }
-        }
-    }
-    if (nchunk > 0) store_chunk(sa, 0);
-    if (nchunk > 1) load_chunk(sa, 1);
-    __syncthreads();
-    D2T_KSTAMP(2);
-    D2T_KSTAMP_ONLY(unsigned long long k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0, tl = 0, tm = 0, ts = 0, tb = 0;)
-    auto chunk = [&](int c, Stage& nxt, Stage& nxt2) {               // nxt holds chunk c+1 (requested one chunk ago), nxt2 is free
-        const int buf = c & 1;
-        D2T_KCLK(k0);
-        if (c + 2 < nchunk) load_chunk(nxt2, c + 2);
-        D2T_KCLK(k1);
-        const int ne = total - c * EC < EC ? total - c * EC : EC;
-        const int nks = ne >> 2;                                     // uniform; the list is padded to whole k-steps
-        struct KOp { int jb; float sc; float a[NCT]; };
-        auto kfetch = [&](KOp& o, int ks) {
-            const int e = 4 * ks + g;
-            o.jb = ejb[buf][e][j];
-            o.sc = esc[buf][e][j];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) o.a[ct] = A[buf][j][e][16 * ct + n];
-        };
-        auto kstep = [&](const KOp& o) {
-            const int j0 = __builtin_amdgcn_readlane(o.jb, 0);       // the k-step's first entry is never padding
-            const int ik = j0 >> 24;
-            if (ik != i_acc) { flush(); i_acc = ik; }                // wave-uniform: the list has moved on to the next bin row
-            const int tm = (j0 | __builtin_amdgcn_readlane(o.jb, 16) | __builtin_amdgcn_readlane(o.jb, 32) | __builtin_amdgcn_readlane(o.jb, 48)) & (1 << 17);
-            if (!tm) return;                                         // no hit of this k-step reaches the tile in bin column j
-            const float b = (unsigned)(n + 256 - (o.jb & 0x1ff)) < (((unsigned)o.jb >> 9) & 0xffu) ? o.sc : 0.f;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[ct], b, acc[ct], 0, 0, 0);
-        };
-        KOp ka, kb;
-        if (nks > 0) kfetch(ka, 0);
-        for (int ks = 0; ks < nks; ks += 2) {
-            if (ks + 1 < nks) kfetch(kb, ks + 1);
-            kstep(ka);
-            if (ks + 1 >= nks) break;
-            if (ks + 2 < nks) kfetch(ka, ks + 2);
-            kstep(kb);
-        }
-        D2T_KCLK(k2);
-        if (c + 1 < nchunk) store_chunk(nxt, buf ^ 1);
-        D2T_KCLK(k3);
-        __syncthreads();
-        D2T_KCLK(k4);
-        D2T_KSTAMP_ONLY(tl += k1 - k0; tm += k2 - k1; ts += k3 - k2; tb += k4 - k3;)
-    };
-    for (int c = 0; c < nchunk; c += 2) {
-        chunk(c, sa, sb);
-        if (c + 1 < nchunk) chunk(c + 1, sb, sa);
-    }
-    flush();
-    __syncthreads();
-    D2T_KSTAMP(3);
-    D2T_KSTAMP_PUT(5, tl); D2T_KSTAMP_PUT(6, tm); D2T_KSTAMP_PUT(7, ts); D2T_KSTAMP_PUT(8, tb); D2T_KSTAMP_PUT(9, (unsigned long long)nchunk);
-
-    // ---- 3. thread = input channel ch >= 1: its planes are added from the highest m down = ascending bin, two planes per trip (both
-    // fetched before either is added).  (Testing all 48 bins and adding under the test -- the first version -- made every wave walk 48
-    // dependent LDS round trips per channel: 27 k cycles of a 60 k-cycle workgroup.)
-    const bool whole = x0 + 16 <= W;
-#pragma unroll
-    for (int k = 0; k < NCHI; ++k) {
-        const int ch = 1 + tid + k * PT_THREADS;
-        if (1 + k * PT_THREADS >= nch) break;                        // uniform
-        unsigned mask = cmask[k];
-        const float chf = (float)ch;
-        f32x4 o[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        const f32x4* zero4 = reinterpret_cast<const f32x4*>(part);   // (never added)
-        while (__any(mask != 0)) {
-            const int m1 = mask ? 32 - __builtin_clz(mask) : 0;
-            mask &= m1 ? ~(1u << (m1 - 1)) : 0u;
-            const int m2 = mask ? 32 - __builtin_clz(mask) : 0;
-            mask &= m2 ? ~(1u << (m2 - 1)) : 0u;
-            const int b1 = (int)(chf * __builtin_amdgcn_rcpf((float)(m1 ? m1 : 1)) + 0.25f), b2 = (int)(chf * __builtin_amdgcn_rcpf((float)(m2 ? m2 : 1)) + 0.25f);
-            const f32x4* p1 = m1 ? reinterpret_cast<const f32x4*>(part + ((size_t)b1 * nT + (m1 - 1)) * 16) : zero4;
-            const f32x4* p2 = m2 ? reinterpret_cast<const f32x4*>(part + ((size_t)b2 * nT + (m2 - 1)) * 16) : zero4;
-            const f32x4 v0 = p1[0], v1 = p1[1], v2 = p1[2], v3 = p1[3], w0 = p2[0], w1 = p2[1], w2 = p2[2], w3 = p2[3];
-            if (m1) { o[0] += v0; o[1] += v1; o[2] += v2; o[3] += v3; }
-            if (m2) { o[0] += w0; o[1] += w1; o[2] += w2; o[3] += w3; }
-        }
-        if (ch < nch) {
-            float* dst = gin + ((size_t)ch * H + y) * W + x0;
-            if (whole) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4u*>(dst + 4 * q) = o[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (x0 + 4 * q + r < W) dst[4 * q + r] = o[q][r];
-            }
-        }
-    }
-    if (tid < 16 && x0 + tid < W) {                                  // channel 0: bin 0 of every target, ascending t; thread = column
-        float a = 0.f;
-        for (int t0 = 0; t0 < nT; t0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = t0 + k < nT ? part[(size_t)(t0 + k) * 16 + tid] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a = t0 + k < nT ? a + v[k] : a;
-        }
-        gin[(size_t)y * W + x0 + tid] = a;
-    }
-    D2T_KSTAMP(4);
-}
-
-static int ps_tiles_ec(int R, int nT)                                // hits per chunk: 32 where the LDS holds it
-{
-    return ps_tiles_lds(R, nT, 32) <= (size_t)LDS_MAX ? 32 : 16;
-}
-
-static bool psroipool_bwd_tiles_supported(int R, int nT, int H, int W, int k)
-{
-    return k == KT && R >= 1 && R <= PT_MAXR && nT >= 1 && nT <= 32 && H >= 1 && H <= 255 && W >= 1 && W <= 255 &&
-           1LL * R * nT * KK * 4 < 0x7ffffff0LL && 1LL * nT * KK * H * W < 0x7fffffffLL && ps_tiles_lds(R, nT, 16) <= (size_t)LDS_MAX;
-}
-
-static int psroipool_bwd_tiles_f32(const float* gout, const float* rois, float* gin, int R, int nT, int H, int W, hipStream_t st)
-{
-    const int xtiles = (W + 15) / 16, ec = ps_tiles_ec(R, nT);
-    const size_t lds = ps_tiles_lds(R, nT, ec);
-#define D2T_LAUNCH_PT(NCTV, ECV)                                                                                                   \
-    {                                                                                                                              \
-        D2T_ENSURE_DYNAMIC_LDS((k_ps_bwd_tiles<NCTV, ECV>), LDS_MAX);                                                              \
-        hipLaunchKernelGGL((k_ps_bwd_tiles<NCTV, ECV>), dim3(H * xtiles), dim3(PT_THREADS), lds, st, gout, rois, gin, R, nT, H, W, xtiles); \
-    }
-    if (nT <= 16) { if (ec == 32) D2T_LAUNCH_PT(1, 32) else D2T_LAUNCH_PT(1, 16) }
-    else { if (ec == 32) D2T_LAUNCH_PT(2, 32) else D2T_LAUNCH_PT(2, 16) }
-#undef D2T_LAUNCH_PT
-    return launch_status();
-}
+// The TILE form (one launch, the planes of a (map row, 16 columns) tile kept in LDS and gathered there: lab/csrc/d2t_ps_bwd_tiles.inc) was
+// built and measured in round 6 and lost to the row form above (29.7 against 23.6 us at R = 300, nT = 21; profiles/r06_ps_bwd_tiles_lost.txt).
+// Scan builds (-DD2T_ENV_KNOBS) still compile it: D2T_PS_BWD=tiles.
+#ifdef D2T_ENV_KNOBS
+#include "../../lab/csrc/d2t_ps_bwd_tiles.inc"
+#else
+static bool psroipool_bwd_tiles_supported(int, int, int, int, int) { return false; }
+static int psroipool_bwd_tiles_f32(const float*, const float*, float*, int, int, int, int, hipStream_t) { return D2T_EINVAL; }
+#endif
 
 // Which of the three backward designs runs (ps_bwd_design below).  History of the sorted lists vs the planes:
 // the sorted-corner-list kernels (d2t_pool_sorted.hip) do
 // work proportional to the RoI corners per plane (4R) plus a fixed cost of three launches and a
 // 49-workgroup sort; the plane kernels above walk every RoI's rows.  Measured crossover on MI355X
-// (38x75 map, R in 300..3000 x nT in 4..31, tools/ps_scan.py): the sorted design wins from 16 targets
+// (38x75 map, R in 300..3000 x nT in 4..31, lab/tools/ps_scan.py): the sorted design wins from 16 targets
 // up once R * nT reaches ~16000 (R=1000 nT=16: 68 vs 89 us; R=3000 nT=31: 158 vs 277 us) and loses
 // below 8 targets at every R (R=3000 nT=4: 94 vs 59 us).
 // D2T_PS_BWD=planes|sorted|gemm overrides the choice (a lab knob for that measurement, read once).
@@ -1846,7 +1493,7 @@ static int ps_bwd_design(int R, int nT, int H, int W, int k)
     if (f == 3 && g) return 2;
     if (f == 2 && s) return 1;
     if (f == 1 && p) return 0;
-    // measured grid R in {300..3000} x nT in {4..31} on a 38x75 map (tools/ps_scan.py, profiles/r02_b_ps_bwd_scan_*):
+    // measured grid R in {300..3000} x nT in {4..31} on a 38x75 map (lab/tools/ps_scan.py, profiles/r02_b_ps_bwd_scan_*):
     // the GEMM wins from 12 targets up at every R (R=300 nT=16: 33 vs 40 us; R=3000 nT=31: 73 vs 148 sorted / 278 planes)
     // and from 8 targets at R >= 1000; the plane kernels keep the small shapes (R=300 nT=4: 15 vs 25 us)
     if (rw && f == 0 && !(g && nT > 16 && R >= 1500)) return 3;        // round 5: the row form -- except more than 16 targets (two c-tiles per wave) x thousands of RoIs

@@ -198,10 +198,10 @@ k_roipool_fwd_sat(const float* __restrict__ fm, const float* __restrict__ rois, 
 // owns a bin and produces both channels: a corner is ONE ds_read_b128 for two outputs instead of two
 // ds_read_b64 -- half the LDS instructions of the look-up phase, and 16-byte accesses at RoI-dependent
 // addresses conflict less than 8-byte ones (the planar kernel's SQ_LDS_BANK_CONFLICT is 52 % of its LDS time).
-// Round 5, what the workgroup's clocks say (tools/kstamps.py, profiles/r05_c_kstamps_roipool_fwd_*.txt; config 3, cycles per workgroup):
+// Round 5, what the workgroup's clocks say (lab/tools/kstamps.py, profiles/r05_c_kstamps_roipool_fwd_*.txt; config 3, cycles per workgroup):
 // planes into LDS 8.6 k, prefix2d 8.0 k, geometry of 240 RoIs 4.1 k, look-ups 8.1 k, geometry of the last 60 5.4 k, look-ups 3.0 k =
 // 37.7 k = 16 us, two workgroups per CU (512 in all).  The stamped build runs them one at a time, the product kernel (60 VGPRs) two at a time --
-// csrc/lab/occ_lab: a CU holds two 1,024-thread workgroups of 56 KB up to 64 VGPRs -- which changes little: prefix and look-ups are LDS-bound and
+// lab/csrc/occ_lab: a CU holds two 1,024-thread workgroups of 56 KB up to 64 VGPRs -- which changes little: prefix and look-ups are LDS-bound and
 // co-resident workgroups share the LDS pipe.  Measured and dropped: the geometry of all RoIs evaluated under the plane loads' latency (workgroup
 // 37.7 k -> 29.7 k cycles, but the op 31.4 -> 34.2 us); the 2-D prefix as wave-wide f64 row scans (12.7 k cycles against 8.0 k); workgroups of
 // 832 / 768 / 640 / 512 threads (33.4 / 31.4 / 33.1 / 35.5 us against 31.8).
@@ -337,7 +337,7 @@ static bool sat2_anyk(int C, int H, int W, int k)
 // Nor did a thread-per-output kernel whose bin rows are fetched by eight independent loads before they are added (20.2 against 21.9 us at R = 8,
 // 28.9 against 26.0 at R = 16): the generic kernel is not waiting on a dependent chain either.
 #ifdef D2T_ENV_KNOBS
-// scan builds: what the runtime says about the residency of the interleaved summed-area kernel (tools/kstamps.py roipool_occupancy)
+// scan builds: what the runtime says about the residency of the interleaved summed-area kernel (lab/tools/kstamps.py roipool_occupancy)
 extern "C" int d2t_lab_roipool_fwd_occupancy(int H, int W, int threads, int* blocks, int* regs, int* static_lds, int* dyn_lds)
 {
     const SatLayout L = sat_layout(2, H, W, GEO8);

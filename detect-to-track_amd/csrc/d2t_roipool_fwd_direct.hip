@@ -117,7 +117,7 @@ k_roipool_fwd_direct(const float* __restrict__ fm, const float* __restrict__ roi
         }
         // sum / float(binNumel), :60-61 (a product of two negative extents is positive, as there; n == 0: 0 / 0 = NaN).  IEEE division is ~11
         // instructions; the 8 sums of a bin share the divisor, so: r = 1 / n once (IEEE), then q0 = a r, q = fma(fma(-n, q0, a), r, q0) --
-        // the correctly rounded quotient whenever q0 is zero or 1e-30 < |q0| < 1e30 (csrc/lab/div_lab.hip: 0 mismatches against the
+        // the correctly rounded quotient whenever q0 is zero or 1e-30 < |q0| < 1e30 (lab/csrc/div_lab.hip: 0 mismatches against the
         // compiler's division in 1.4e11 pairs, every n in +-[1, 65025]; a = -0 is the one exception and cannot be a running sum that
         // started at +0).  Anything else -- denormal or huge quotients, Inf, NaN, n == 0 -- takes the plain division (cold).
         const float nf = static_cast<float>(h * w);

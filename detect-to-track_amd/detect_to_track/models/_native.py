@@ -22,7 +22,7 @@ _LIB_ENV = "D2T_OPS_LIBRARY"
 _DEFAULT = _HERE.parent.parent / "lib" / "libd2t_ops.so"
 
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA, IMPL_FAST = 0, 1, 2, 5       # include/d2t_ops.h
-# selectors of the LAB build only (csrc/lab/d2t_lab_selectors.h; `make -C csrc lab`, D2T_OPS_LIBRARY=.../lib_lab/libd2t_ops.so):
+# selectors of the LAB build only (lab/csrc/d2t_lab_selectors.h; `make -C csrc lab`, D2T_OPS_LIBRARY=.../lib_lab/libd2t_ops.so):
 # the product library rejects them with D2T_EINVAL
 LAB_IMPL_STRIP16, LAB_IMPL_BF16X3, LAB_IMPL_WIDE8, LAB_IMPL_STRIP4 = 3, 4, 6, 7
 

@@ -104,7 +104,7 @@ enum { D2T_IMPL_AUTO = 0, D2T_IMPL_GENERIC = 1, D2T_IMPL_MFMA = 2, D2T_IMPL_FAST
  *                    opt-in.
  * Any other value is D2T_EINVAL.  (ABI 1.05 also enumerated 3, 4, 6, 7: one specific correlation-backward kernel each, for A/B
  * measurements.  Those kernels lost their measurements and left the product library in 1.06; they build into the LAB library only --
- * `make -C detect-to-track_amd/csrc lab`, selectors in csrc/lab/d2t_lab_selectors.h.) */
+ * `make -C detect-to-track_amd/csrc lab`, selectors in lab/csrc/d2t_lab_selectors.h.) */
 
 /* ---------------- PointwiseCorrelation ---------------- */
 size_t d2t_corr_fwd_workspace_bytes(int B, int C, int H, int W, int d, int stride, int elem_size);

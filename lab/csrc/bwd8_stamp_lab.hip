@@ -3,7 +3,7 @@
 // the chip holds under this load (s_memtime / s_memrealtime).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DD2T_LAB lab/bwd8_stamp_lab.hip -o lab/bwd8_stamp_lab
 #define D2T_LAB 1
-#include "../d2t_corr_bwd8.hip"
+#include "../../detect-to-track_amd/csrc/d2t_corr_bwd8.hip"
 #include <algorithm>
 #include <cstdio>
 #include <vector>

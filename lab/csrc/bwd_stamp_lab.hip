@@ -2,9 +2,9 @@
 // per-wave clock reads and prints where the waves of a workgroup of the metric shape spend their cycles.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DD2T_LAB -DD2T_LAB_KERNELS lab/bwd_stamp_lab.hip -o lab/bwd_stamp_lab
 #define D2T_LAB 1
-#include "../d2t_corr_tuned.hip"
-#include "../d2t_corr_fwd_band.hip"     // the rest of the correlation units the tuned one links against
-#include "../d2t_corr_bwd8.hip"
+#include "../../detect-to-track_amd/csrc/d2t_corr_tuned.hip"
+#include "../../detect-to-track_amd/csrc/d2t_corr_fwd_band.hip"     // the rest of the correlation units the tuned one links against
+#include "../../detect-to-track_amd/csrc/d2t_corr_bwd8.hip"
 #include "d2t_corr_bwd8w.hip"
 #include "d2t_corr_bwd8bf.hip"
 #include <algorithm>

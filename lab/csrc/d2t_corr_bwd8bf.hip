@@ -3,7 +3,7 @@
 //     gX[c][t] = sum over window slots w of  G[t][w] * S[c][w]
 // but every f32 operand x is carried as three bf16 pieces, x = hi + mid + lo exactly (8 + 8 + 8 mantissa bits), and a
 // product keeps six of the nine piece products (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi; the dropped ones are below
-// 2^-24 of the product), accumulated in f32 by v_mfma_f32_16x16x32_bf16.  Measured in csrc/lab/bf16x3_lab: 24 such MFMAs
+// 2^-24 of the product), accumulated in f32 by v_mfma_f32_16x16x32_bf16.  Measured in lab/csrc/bf16x3_lab: 24 such MFMAs
 // do the K = 128 of 32 v_mfma_f32_16x16x4_f32 in 0.46x the time (wall clock), and the result is as close to the exact sum as the f32
 // chain is (<= 1.1e-6 of sum|terms| at K = 2048 against 1.7e-6).  The backward's contract is 1e-5 (the reference adds with
 // atomics in no fixed order); this kernel is deterministic like the f32 one.
@@ -25,7 +25,7 @@
 // Non-finite inputs: a piece of Inf / NaN is NaN, the tile's accumulators become non-finite and the wave repairs its
 // region in the reference's form (strip_repair), as in the f32 kernels.  Finite values above the bf16 range (> 3.39e38)
 // take that path too.
-#include "../d2t_corr_common.hpp"
+#include "../../detect-to-track_amd/csrc/d2t_corr_common.hpp"
 #include <type_traits>
 
 namespace d2t { namespace tuned {

@@ -5,7 +5,7 @@
 // role 0 (gradFM0): t = centre pixels, S = FM1;  role 1 (gradFM1): t = displaced pixels, S = FM0.
 //
 // Why wider strips.  The 4-pixel strip kernel is co-limited by the matrix pipe and by the request rate between a
-// CU's vector L1 and the L2 (csrc/lab/ta_lab + PMC, DESIGN 5: about 2.8 cycles per 128-byte request and CU; the
+// CU's vector L1 and the L2 (lab/csrc/ta_lab + PMC, DESIGN 5: about 2.8 cycles per 128-byte request and CU; the
 // 4-pixel kernel makes 10.6 M of them per launch, 0.65 of what the chip can serve in its 70 us).  Most are the
 // feature (S) stream: a 4-pixel strip needs an 80-byte window row per channel, fetched as a 64-byte piece (1.47
 // lines at 4-byte alignment) plus a 16-byte piece (1.09 lines) = 2.56 requests per (channel, row) for 4 pixels.
@@ -24,7 +24,7 @@
 // enumeration with G = 0 (their S operand is whatever lies there -- the neighbouring row, or the range check's
 // zeros); a non-finite value there is caught by the same repair path as any other (d2t_corr_common.hpp).  A piece
 // that straddles the END of the last channel's last row keeps its in-range dwords (per-dword range check).
-#include "../d2t_corr_common.hpp"
+#include "../../detect-to-track_amd/csrc/d2t_corr_common.hpp"
 #include <type_traits>
 
 namespace d2t { namespace tuned {

@@ -2,9 +2,9 @@
 // in-kernel stamps and prints where a workgroup of the metric shape spends its cycles.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DD2T_LAB lab/fwd_lab.hip -o lab/fwd_lab
 #define D2T_LAB 1
-#include "../d2t_corr_tuned.hip"
-#include "../d2t_corr_fwd_band.hip"     // the rest of the correlation units the tuned one links against
-#include "../d2t_corr_bwd8.hip"
+#include "../../detect-to-track_amd/csrc/d2t_corr_tuned.hip"
+#include "../../detect-to-track_amd/csrc/d2t_corr_fwd_band.hip"     // the rest of the correlation units the tuned one links against
+#include "../../detect-to-track_amd/csrc/d2t_corr_bwd8.hip"
 #include <algorithm>
 #include <cstdio>
 #include <vector>

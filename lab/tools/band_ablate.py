@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Band-split forward at the metric shape: time per call with parts of the kernel switched off (stamp build: -DD2T_ENV_KNOBS -DD2T_BAND_STAMPS).
     make -C detect-to-track_amd/csrc -j8 OUT=../lib_stamps EXTRA="-DD2T_ENV_KNOBS -DD2T_BAND_STAMPS"
-    D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_stamps/libd2t_ops.so python3 tools/band_ablate.py [cfg,cfg,...] [BxCxHxW]
+    D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_stamps/libd2t_ops.so python3 lab/tools/band_ablate.py [cfg,cfg,...] [BxCxHxW]
 Ablation bits: 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads from LDS, 8 no stores (results are wrong by design; only the time is read)."""
 import ctypes
 import os
@@ -10,7 +10,7 @@ from pathlib import Path
 
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
 from detect_to_track.models import _native  # noqa: E402
 

@@ -2,7 +2,7 @@
 """Scan of the band-split forward (csrc/d2t_corr_fwd_band.hip) over workgroup shapes: bit-exactness against the generic kernel
 (both layouts) and time per call, next to the default dispatch of the product library.  Needs a knob build:
     make -C detect-to-track_amd/csrc -j8 OUT=../lib_knobs EXTRA=-DD2T_ENV_KNOBS
-    gpurun -- 'D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 tools/band_scan.py'
+    gpurun -- 'D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 lab/tools/band_scan.py'
 (D2T_BAND_CFG is read per call by that build: 0 = the segment kernels, 41 = TW 4 x NB 1, ...)."""
 import os
 import sys
@@ -10,7 +10,7 @@ from pathlib import Path
 
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
 from detect_to_track.models import _ext, _native  # noqa: E402
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-kernel clock reads of the band-split forward (scan build, -DD2T_ENV_KNOBS): where a workgroup's time goes.
-    D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 tools/band_stamps.py [cfg,cfg,...]"""
+    D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 lab/tools/band_stamps.py [cfg,cfg,...]"""
 import ctypes
 import os
 import sys
@@ -9,7 +9,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
 from detect_to_track.models import _native  # noqa: E402
 

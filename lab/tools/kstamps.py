@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-kernel clock reads (knob build, -DD2T_ENV_KNOBS) of the pooling kernels: where a workgroup's time goes.
-    D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 tools/kstamps.py roipool_fwd"""
+    D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 lab/tools/kstamps.py roipool_fwd"""
 import ctypes
 import sys
 from pathlib import Path
@@ -8,7 +8,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
 from detect_to_track.models import _native  # noqa: E402

@@ -4,7 +4,7 @@ and FAST, forward and backward."""
 import sys
 from pathlib import Path
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "detect-to-track_amd")); sys.path.insert(0, str(ROOT))
 from detect_to_track.models import _ext, _native  # noqa: E402
 from bench_ops import timed  # noqa: E402

@@ -1,7 +1,7 @@
 """dev helper: what does ONE Inf in a feature map cost the tuned backward correlation (repair path)?"""
 import sys, torch
 from pathlib import Path
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "detect-to-track_amd")); sys.path.insert(0, str(ROOT))
 from detect_to_track.models import _ext
 from bench_ops import timed

@@ -1,7 +1,7 @@
 """dev helper: PSROIPool backward time over (R, nT) for the design picked by D2T_PS_BWD (events, C ABI)."""
 import os, sys, torch, numpy as np
 from pathlib import Path
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "detect-to-track_amd")); sys.path.insert(0, str(ROOT))
 from detect_to_track.models import _native
 from bench_ops import random_rois, timed, _ws

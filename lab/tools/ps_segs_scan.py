@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """PSROIPool backward, row form: time over the number of RoI ranges per task (scan build; D2T_PS_SEGS is read per call), with a check
 against the reference-order kernels first.
-    D2T_PS_BWD=rows D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 tools/ps_segs_scan.py"""
+    D2T_PS_BWD=rows D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 lab/tools/ps_segs_scan.py"""
 import os
 import sys
 from pathlib import Path
 
 import torch
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "detect-to-track_amd"))
 sys.path.insert(0, str(ROOT))
 from detect_to_track.models import _native  # noqa: E402

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""ROIPool backward alone at config 3 (R = 300, C = 1024, 38 x 63, k = 7) -- the program tools/pmc_roi.sh profiles."""
+"""ROIPool backward alone at config 3 (R = 300, C = 1024, 38 x 63, k = 7) -- the program lab/tools/pmc_roi.sh profiles."""
 import sys
 from pathlib import Path
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "detect-to-track_amd")); sys.path.insert(0, str(ROOT))
 from detect_to_track.models import _ext  # noqa: E402
 from bench_ops import random_rois, timed  # noqa: E402

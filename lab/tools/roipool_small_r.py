@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """LOST experiment of round 5 (kept for the record; the kernels and the knobs D2T_ROI_FEW_MAXR / D2T_ROI_FEW_OFF it drove are no longer in the library:
-csrc/lab/roipool_fwd_few.inc, profiles/r05_e_roipool_few_rois_lost.txt).  ROIPool forward at few RoIs (the tracker's eval path): the boxes-through-LDS kernel against the reference-order kernel (bit for bit)
+lab/csrc/roipool_fwd_few.inc, profiles/r05_e_roipool_few_rois_lost.txt).  ROIPool forward at few RoIs (the tracker's eval path): the boxes-through-LDS kernel against the reference-order kernel (bit for bit)
 and against the summed-area kernel (time).  Scan build (D2T_ROI_FEW_MAXR / D2T_ROI_FEW_OFF are read per call):
     D2T_OPS_LIBRARY=$PWD/detect-to-track_amd/lib_knobs/libd2t_ops.so python3 tools/roipool_small_r.py"""
 import os

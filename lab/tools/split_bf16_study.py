@@ -7,7 +7,7 @@ in f32 -- accumulated in f32 (what v_mfma_f32_16x16x32_bf16 delivers; the order 
 terms are added in channel order).  Compared with the reference's f32 FMA chain (pointwise_correlation_cuda.cu:105-107)
 and with the exact (f64) dot product, on the metric's input distribution U[0,1) and on zero-mean data.
 
-    python tools/split_bf16_study.py            # CPU, numpy, a few seconds
+    python lab/tools/split_bf16_study.py            # CPU, numpy, a few seconds
 """
 import numpy as np
 

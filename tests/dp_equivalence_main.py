@@ -36,7 +36,7 @@ def build(dev, buckets_factory=None):
     # MIOpen / rocBLAS may pick kernels that add partial sums with atomics (GEMM-based convolutions, split-K): the step is then not even
     # reproducible between two runs of the SAME process layout, and a rounding-level difference in the RPN outputs can flip a region
     # (top-k / NMS / a bin's floor or ceil) -- measured: 1e-2 of a parameter's largest gradient between two identical single-process runs,
-    # tools/lab/step_determinism.py.  Ask for deterministic library kernels, so that what is compared is the data-parallel arithmetic.
+    # lab/tools/step_determinism.py.  Ask for deterministic library kernels, so that what is compared is the data-parallel arithmetic.
     torch.backends.cudnn.deterministic = True
     torch.backends.cudnn.benchmark = False
     torch.manual_seed(0)                         # the SAME initial weights in every process

@@ -1,4 +1,4 @@
-"""GPU tests of the LAB kernels (csrc/lab/: strips 8 pixels wide, bf16x3, the round-2 16-wave strip kernel) -- correlation backward
+"""GPU tests of the LAB kernels (lab/csrc/: strips 8 pixels wide, bf16x3, the round-2 16-wave strip kernel) -- correlation backward
 kernels that lost their A/B measurements and left the product library in ABI 1.06.  They run only against the LAB build:
 
     make -C detect-to-track_amd/csrc lab
@@ -86,7 +86,7 @@ def test_bf16x3_backward_nonfinite_and_huge_inputs(oracle):
         torch.testing.assert_close(got[fin], want[fin], rtol=2e-5, atol=2e-3)   # elements next to the 3.4e38 values are ~1e37; the rest ~50
 
 
-WIDE8, STRIP4 = 6, 7        # csrc/lab/d2t_lab_selectors.h: the two 8-wave backward kernels, demanded
+WIDE8, STRIP4 = 6, 7        # lab/csrc/d2t_lab_selectors.h: the two 8-wave backward kernels, demanded
 
 
 @pytest.mark.parametrize("impl", [WIDE8, STRIP4], ids=["wide8", "strip4"])

@@ -2,7 +2,7 @@
 # Everything a round's final profiles/<tag>_* set is made from.  Run on the GPU box:  gpurun --timeout 1200 -- 'bash tools/profile_round.sh <tag>'
 #   1. kernel durations (rocprofv3 --kernel-trace --stats) of bench.py (the metric workload) and bench_ops.py (every op / shape)
 #   2. separate --pmc passes of bench.py: HBM bytes (FETCH_SIZE / WRITE_SIZE), L1<->L2 requests, TA / MFMA / LDS / wait counters
-#   3. the third roof: tools/ta_roof.sh (csrc/lab/ta_lab under the same counters) -> ta_roof.json
+#   3. the third roof: tools/ta_roof.sh (lab/csrc/ta_lab under the same counters) -> ta_roof.json
 #   4. rocprof HBM bytes of every op / shape / direction of bench_ops.py (tools/ops_pmc.sh), folded into profiles/traffic.json
 #   5. the bench line in the driver's form (--steps 20 --warmup 5) and with 200 steps, bench_ops.jsonl, the config-4 step
 tag=${1:-r04}

@@ -2,7 +2,7 @@
 """Reduce the passes of tools/ta_roof.sh to profiles/ta_roof.json (what bench.py's roofline_ta reads).
 
 A "line" here is one request between a CU's vector L1 and the XCD's L2: TCP_TCC_READ_REQ (one per 128-byte line an instruction
-misses) + TCP_TCC_WRITE_REQ (one per contiguous run inside a 64-byte sector).  csrc/lab/ta_lab calibrates both the unit and the
+misses) + TCP_TCC_WRITE_REQ (one per contiguous run inside a 64-byte sector).  lab/csrc/ta_lab calibrates both the unit and the
 peak: with every CU streaming, the request rate is the SAME for 1 KB contiguous per wave-instruction (8 requests) and for 16
 channels x 64 bytes at 4-byte alignment (23.5 requests) -- about 2.8 cycles per request and CU -- while the tag-access counter
 (TCP_TOTAL_CACHE_ACCESSES) follows the lane order, not the time.  peak_lines_per_s = that rate (requests of the PMC pass / wall time
@@ -46,7 +46,7 @@ def main():
         if m:
             wall.setdefault(int(m.group(1)), []).append(float(m.group(2)))
     res = {"_note": "tools/ta_roof.sh + tools/ta_roof.py; lines = L1<->L2 requests per launch = TCP_TCC_READ_REQ (128-byte line fills) + "
-                    "TCP_TCC_WRITE_REQ; peak = the request rate csrc/lab/ta_lab sustains with every CU streaming (map 3: 1 KB contiguous "
+                    "TCP_TCC_WRITE_REQ; peak = the request rate lab/csrc/ta_lab sustains with every CU streaming (map 3: 1 KB contiguous "
                     "per wave-instruction; maps 0-2 reach the same rate): requests of the PMC pass / wall time of the un-profiled run",
            "lab": {}}
     peak = None

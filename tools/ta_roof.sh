@@ -1,15 +1,15 @@
 #!/bin/bash
 # The third roof of bench.py's line: L1 / texture-address cache-line rate.
 #   gpurun --timeout 900 -- 'bash tools/ta_roof.sh <tag>'
-# 1. csrc/lab/ta_lab: every CU streams 16-byte pieces; wall time per wave-instruction for four lane->address maps, and the
+# 1. lab/csrc/ta_lab: every CU streams 16-byte pieces; wall time per wave-instruction for four lane->address maps, and the
 #    same launches under rocprofv3 --pmc (TCP_TOTAL_CACHE_ACCESSES = cache-line tag accesses, TA busy / buffer cycles,
 #    GRBM_GUI_ACTIVE for the clock): peak = the line rate of the whole-line stream (map 3).
 # 2. bench.py under the same counters: lines per launch of k_corr_fwd_seg / k_corr_bwd_strip8.
 # 3. tools/ta_roof.py writes profiles/ta_roof.json from both.
 tag=${1:-r04}
 root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/ta_$tag; mkdir -p $out
-lab=$root/detect-to-track_amd/csrc/lab/ta_lab
-[ -x $lab ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -o $lab $root/detect-to-track_amd/csrc/lab/ta_lab.hip || exit 1
+lab=$root/lab/csrc/ta_lab
+[ -x $lab ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -o $lab $root/lab/csrc/ta_lab.hip || exit 1
 $lab > $out/ta_lab_wall.txt 2>&1 || exit 1
 cat $out/ta_lab_wall.txt
 cd /tmp && export TMPDIR=/tmp
