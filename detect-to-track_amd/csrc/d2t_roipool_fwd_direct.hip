@@ -110,7 +110,8 @@ k_roipool_fwd_direct(const float* __restrict__ fm, const float* __restrict__ roi
             p += RD_CG;
             if (xx == w) { xx = 0; p += skip; }
             const float* pn = s + 1 < cnt ? p : px;
-            const f32x4 an = *reinterpret_cast<const f32x4*>(pn), bn = *reinterpret_cast<const f32x4*>(pn + 4);
+            f32x4 an = a, bn = b;
+            if (!(D2T_KDBG & 2)) { an = *reinterpret_cast<const f32x4*>(pn); bn = *reinterpret_cast<const f32x4*>(pn + 4); }   // (scan builds: ablation bit 2 = no LDS reads in the walk)
             acc[0] += f32x2{a[0], a[1]}; acc[1] += f32x2{a[2], a[3]};
             acc[2] += f32x2{b[0], b[1]}; acc[3] += f32x2{b[2], b[3]};
             a = an; b = bn;
@@ -123,21 +124,30 @@ k_roipool_fwd_direct(const float* __restrict__ fm, const float* __restrict__ roi
         const float nf = static_cast<float>(h * w);
         const float rn = 1.0f / nf;
         float res[RD_CG];
-        bool safe = true;
+        // safe for all 8 sums?  |a| (as an integer: NaN and Inf are the largest patterns) below 1e30, and every NON-zero |a| at least 1e-25
+        // (then |q0| >= 1e-25 / 65025 > 1e-30): one max and one min over the patterns, zero wrapping to the largest value in the min
+        unsigned big = 0u, small = 0xffffffffu;
 #pragma unroll
         for (int c = 0; c < RD_CG; ++c) {
             const float a = acc[c >> 1][c & 1];
             const float q0 = a * rn;
             res[c] = __builtin_fmaf(__builtin_fmaf(-nf, q0, a), rn, q0);
-            const float m = __builtin_fabsf(q0);
-            safe = safe && m < 1e30f && (m > 1e-30f || q0 == 0.0f);
+            const unsigned t = __builtin_bit_cast(unsigned, a) & 0x7fffffffu;
+            big = t > big ? t : big;
+            small = t - 1u < small ? t - 1u : small;
         }
+        const bool safe = big < 0x7149f2cau /* 1e30f */ && small >= 0x15f79688u - 1u /* 1e-25f */ && nf >= 1.0f;   // (n <= 0: the plain division)
         if (__builtin_expect(!safe, 0)) {
 #pragma unroll
             for (int c = 0; c < RD_CG; ++c) res[c] = acc[c >> 1][c & 1] / nf;
         }
         float* dst = out + ((size_t)(r_lo + rr) * C + c0) * KK + bin;
-        if (c0 + RD_CG <= C) {                                       // uniform: a whole channel group
+        if (D2T_KDBG & 1) {                                          // (scan builds: ablation bit 1 = no stores)
+            float sink = 0.f;
+#pragma unroll
+            for (int c = 0; c < RD_CG; ++c) sink += res[c];
+            if (sink == 123.456f) dst[0] = sink;
+        } else if (c0 + RD_CG <= C) {                                // uniform: a whole channel group
 #pragma unroll
             for (int c = 0; c < RD_CG; ++c) dst[(size_t)c * KK] = res[c];
         } else {
@@ -151,19 +161,22 @@ k_roipool_fwd_direct(const float* __restrict__ fm, const float* __restrict__ roi
 
 size_t direct_lds(int H, int W, int per) { return (size_t)H * W * RD_CG * 4 + (size_t)per * RD_GEO; }
 
-// RoI shares per channel group: about one workgroup per CU (one round), never more shares than 32-RoI pieces
-void direct_plan(int R, int C, int& gx, int& split, int& per)
+// RoI shares per channel group: about one workgroup per CU (one round) -- or two where two workgroups fit a CU's LDS together (38 x 63:
+// 79 KB each; config 3 30.6 against 31.4 us, while at 38 x 75, 91 KB, a second round of workgroups costs 64 against 58 us:
+// profiles/r06_roipool_direct_ab.txt) --, never more shares than 32-RoI pieces
+void direct_plan(int R, int C, int H, int W, int& gx, int& split, int& per)
 {
     gx = (C + RD_CG - 1) / RD_CG;
-#ifndef RD_WGS
-#define RD_WGS 256
-#endif
-    split = (RD_WGS + gx / 2) / gx;
     const int max_split = (R + 31) / 32;
-    split = split < 1 ? 1 : (split > max_split ? max_split : split);
-    split = split > 65535 ? 65535 : split;
-    per = (R + split - 1) / split;
-    split = (R + per - 1) / per;
+    auto plan = [&](int wgs) {
+        split = (wgs + gx / 2) / gx;
+        split = split < 1 ? 1 : (split > max_split ? max_split : split);
+        split = split > 65535 ? 65535 : split;
+        per = (R + split - 1) / split;
+        split = (R + per - 1) / per;
+    };
+    plan(512);
+    if (2 * direct_lds(H, W, per) > (size_t)LDS_MAX) plan(256);
 }
 
 }  // namespace
@@ -172,14 +185,14 @@ bool roipool_fwd_direct_supported(int R, int C, int H, int W, int k)
 {
     if (!(k == KT && R >= 1 && C >= 1 && H >= 1 && W >= 1 && H <= 255 && W <= 255)) return false;
     int gx, split, per;
-    direct_plan(R, C, gx, split, per);
+    direct_plan(R, C, H, W, gx, split, per);
     return direct_lds(H, W, per) <= (size_t)LDS_MAX && 1LL * R * C * KK < 0x7fffffffLL;
 }
 
 int roipool_fwd_direct_f32(const float* fm, const float* rois, float* out, int R, int C, int H, int W, hipStream_t st)
 {
     int gx, split, per;
-    direct_plan(R, C, gx, split, per);
+    direct_plan(R, C, H, W, gx, split, per);
     D2T_ENSURE_DYNAMIC_LDS(k_roipool_fwd_direct, LDS_MAX);
     hipLaunchKernelGGL(k_roipool_fwd_direct, dim3(gx, split), dim3(RD_THREADS), direct_lds(H, W, per), st, fm, rois, out, R, C, H, W, per);
     return launch_status();

@@ -63,9 +63,14 @@ def main():
         R, C, H, W, K = [int(x) for x in sys.argv[2:6]] + [7] if len(sys.argv) > 5 else (300, 1024, 38, 63, 7)
         fm, out = torch.rand(C, H, W, device=dev), torch.empty(R, C, K, K, device=dev)
         rois = torch.from_numpy(bench_ops.random_rois(R, 0)).to(dev)
-        run("d2t_lab_roipool_direct_stamps",
-            lambda: bench_ops._check(lib.d2t_roipool_fwd_f32(fm.data_ptr(), rois.data_ptr(), out.data_ptr(), R, C, H, W, K, 0, 0, 0, st)),
-            ["entry", "planes + geometry in LDS", "bins walked, stored"])
+        call = lambda: bench_ops._check(lib.d2t_roipool_fwd_f32(fm.data_ptr(), rois.data_ptr(), out.data_ptr(), R, C, H, W, K, 0, 0, 0, st))
+        dbg = lib.d2t_lab_roipool_direct_stamps_dbg
+        dbg.restype, dbg.argtypes = ctypes.c_int, [ctypes.c_int]
+        for bits, name in ((0, "product"), (1, "no stores"), (2, "no LDS reads in the walk"), (3, "neither")):
+            assert dbg(bits) == 0
+            print(f"--- ablation {bits}: {name}: op {bench_ops.timed(lambda i: call(), 20, 1):.1f} us (one buffer set: cache-warm)")
+            run("d2t_lab_roipool_direct_stamps", call, ["entry", "planes + geometry in LDS", "bins walked, stored"])
+        assert dbg(0) == 0
     if what == "roipool_bwd":
         R, C, H, W, K = 300, 1024, 38, 63, 7
         go, gin = torch.rand(R, C, K, K, device=dev), torch.empty(C, H, W, device=dev)
