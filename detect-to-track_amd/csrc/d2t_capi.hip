@@ -68,7 +68,7 @@ extern "C" {
 static inline bool ws_misaligned_(const void* ws, size_t ws_bytes) { return ws && ws_bytes && (reinterpret_cast<uintptr_t>(ws) & 15u) != 0; }
 #define ws_misaligned(ws) ws_misaligned_(ws, ws_bytes)   /* checked only where a workspace is passed: ws_bytes = 0 never touches it */
 
-int d2t_version(void) { return 106; }   // 1.06: round 5 -- selectors trimmed to AUTO / GENERIC / MFMA / FAST (3, 4, 6, 7 are rejected: lab build only); band-split forward for small grids
+int d2t_version(void) { return 107; }   // 1.07: round 6 -- ROIPool forward k = 7 in the reference's own order (bit-identical, any number of RoIs); PSROIPool forward needs no workspace where it is one launch
 
 #ifdef D2T_LAB_KERNELS
 int d2t_lab_build(void) { return 1; }   // present in the lab build only (lab/csrc/d2t_lab_selectors.h)

@@ -161,6 +161,8 @@ k_roipool_fwd_direct(const float* __restrict__ fm, const float* __restrict__ roi
 
 size_t direct_lds(int H, int W, int per) { return (size_t)H * W * RD_CG * 4 + (size_t)per * RD_GEO; }
 
+// (16 channels per lane -- half the walk's bookkeeping per output, 16 planes = 153 KB at 38 x 63 -- measured 40.0 against 31.9 us at config 3:
+// profiles/r06_ab_roipool_direct_cg16_lost.txt.)
 // RoI shares per channel group: about one workgroup per CU (one round) -- or two where two workgroups fit a CU's LDS together (38 x 63:
 // 79 KB each; config 3 30.6 against 31.4 us, while at 38 x 75, 91 KB, a second round of workgroups costs 64 against 58 us:
 // profiles/r06_roipool_direct_ab.txt) --, never more shares than 32-RoI pieces

@@ -73,8 +73,9 @@ const char* d2t_error_string(int code);
  * (cfg/default.yaml:48,50: D_MAX 8, K 7; correlation_tracker.py:26: stride 1): correlation d_max = 8, stride 1, W >= 20 (backward: H >= 17 too);
  * pooling k = 7; float32.  Everything else -- and all of float64 -- runs type-generic kernels in the reference's order whose
  * results are bit-identical to the thread-per-element kernels D2T_IMPL_GENERIC selects (tested) -- with ONE exception: the float32
- * ROIPool forward with k <= 16 and at least 32 RoIs stays on the summed-area kernel whatever k is (the contract of k = 7: within 1e-5 of
- * the reference, NaN pattern exact; tests/test_roipool.py::test_forward_any_bin_count_summed_area_tables) -- in two tiers: the default
+ * ROIPool forward with k <= 16, k != 7 and at least 32 RoIs runs the f64 summed-area kernel (within 1e-5 of the reference, NaN pattern exact;
+ * tests/test_roipool.py::test_forward_any_bin_count_summed_area_tables; k = 7 itself is bit-identical since ABI 1.07:
+ * d2t_roipool_fwd_direct.hip) -- in two tiers: the default
  * dispatch takes kernels that share the work the anchor repeats per thread (correlation f32, d_max <= 14: d2t_corr_fwd_mfma.hip /
  * d2t_corr_blocked.hip -- forward tiles with the FM1 window in LDS (d_max <= 8: on the f32 matrix pipe), backward four pixels x four
  * channels per thread from zero-padded row copies; pooling backward, k <= 32: d2t_pool_lists.hip -- per map row the lists of the bin rows / cells
@@ -83,13 +84,13 @@ const char* d2t_error_string(int code);
  *   correlation B=8 C=256 38x63   tuned 46 / 74     d_max=7: 93 / 170 (668 / 6,743)    stride 2: 101 / 200 (787 / 2,539)
  *                                                   f64: 1,217 / 2,068 (1,230 / 11,216)
  *   ROIPool R=300 C=1024 38x63    tuned 31 / 65     k=6: 29 / 121 (168 / 2,346)        f64: 262 / 243 (270 / 3,105)
- *                                 (forward: the summed-area kernel takes any k <= 16 -- within 1e-5 of the reference like k = 7)
+ *                                 (forward: the summed-area kernel takes any k <= 16, k != 7 -- within 1e-5 of the reference; k = 7 is bit-identical)
  *   PSROIPool R=300 nT=21 38x63   tuned 18 / 32     k=6: 18 / 84 (18 / 510)            f64: 25 / 125 (25 / 640)
  * (the Python wrappers warn once when a float32 call leaves the envelope under D2T_IMPL_AUTO).
  *
  * Implementation selector of the f32 entry points (per call, no global state):
  *   D2T_IMPL_AUTO    the tuned gfx950 path when its preconditions hold and it is the faster one
- *                    (ROIPool forward with fewer than 32 RoIs takes the generic kernel), else generic
+ *                    (the summed-area ROIPool forward -- k != 7 -- with fewer than 32 RoIs takes the generic kernel), else generic
  *   D2T_IMPL_GENERIC the type-generic reference-order kernels (also used for f64)
  *   D2T_IMPL_MFMA    the tuned path, demanded: correlation returns D2T_EINVAL when its preconditions
  *                    (d_max = 8, stride 1, W >= 20; backward: H >= 17 as well -- the strip kernel keeps five
