@@ -29,7 +29,7 @@ def test_symbol_exported(name, native):
 
 
 def test_version_and_error_strings(native):
-    assert native.version() >= 100
+    assert native.version() >= 107                    # round 6: exact ROIPool forward, no workspace for the one-launch PSROIPool forward
     assert native.error_string(0) == b"ok"
     for code in (-1, -2, -3):
         assert native.error_string(code) and native.error_string(code) != b"ok"
@@ -94,3 +94,16 @@ def test_header_cites_the_reference_binding():
     for token in ("pointwise_correlation.cpp:23-33", "pointwise_correlation.cpp:36-48", "roipool.cpp:22-32",
                   "roipool.cpp:35-45", "ps_roipool.cpp:23-34", "ps_roipool.cpp:37-47"):
         assert token in HEADER
+
+
+def test_workspace_queries_round6(native):
+    """ABI 1.07: the PSROIPool forward needs NO workspace where it is the one-launch bin-row kernel (a target is one share of <= 1,024 RoIs: the
+    model's class / regression heads, BASELINE config 3) -- ADVICE r5: one predicate for the query and the launcher --, and still asks for the RoI
+    order / the transposed planes elsewhere; the ROIPool forward never needs one."""
+    L = native.lib
+    assert L.d2t_psroipool_fwd_workspace_bytes(300, 21, 38, 63, 7, 4) == 0       # config 3
+    assert L.d2t_psroipool_fwd_workspace_bytes(300, 31, 38, 75, 7, 4) == 0
+    assert L.d2t_psroipool_fwd_workspace_bytes(3000, 4, 38, 75, 7, 4) >= 3000 * 4  # several shares of the RoI list: the order comes from a pre-pass
+    assert L.d2t_psroipool_fwd_workspace_bytes(3, 3, 20, 30, 7, 4) == 0           # small: thread-per-output kernel
+    for R in (8, 300):
+        assert L.d2t_roipool_fwd_workspace_bytes(R, 1891, 38, 75, 7, 4) == 0
