@@ -69,11 +69,12 @@ def test_matches_reference_fixture(path):
     C, H, W = g["fm"].shape
     tol = TOL32 if g["fm"].dtype == np.float32 else TOL64
     out = _n(_ext.roipool_forward(_t(g["fm"]), _t(g["rois"]), k))
-    np.testing.assert_array_equal(out, g["out"])                          # bit-exact, NaNs included (< 32 RoIs: generic)
+    np.testing.assert_array_equal(out, g["out"])                          # bit-exact, NaNs included (k = 7: the direct kernel; else < 32 RoIs: generic)
     gin = _n(_ext.roipool_backward(_t(g["gout"]), _t(g["rois"]), H, W))
     np.testing.assert_allclose(gin, g["gin"], **tol)
     if g["fm"].dtype == np.float32:                                       # the tuned kernels, demanded
-        _assert_fwd(_n(_ext.roipool_forward(_t(g["fm"]), _t(g["rois"]), k, 2)), g["out"], exact=False)
+        # the tuned forward against what the REFERENCE's kernel produced: k = 7 runs the direct kernel (round 6) -- its bits; other k the summed-area tables
+        _assert_fwd(_n(_ext.roipool_forward(_t(g["fm"]), _t(g["rois"]), k, 2)), g["out"], exact=(k == 7 and H * W <= 4800))
         np.testing.assert_allclose(_n(_ext.roipool_backward(_t(g["gout"]), _t(g["rois"]), H, W, 2)), g["gin"], **tol)
     _check_bounds(_n(_ext.roipool_bins(_t(g["rois"]), H, W, k)), g["bounds"])
 
